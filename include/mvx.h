@@ -1,0 +1,132 @@
+/*
+ * mvx: C ABI of the MI355X (gfx950) multi-view triangulation kernels.
+ *
+ * Every entry point takes raw device pointers (float32, contiguous, row-major),
+ * sizes, and the HIP stream to launch on (a hipStream_t passed as void*; NULL is
+ * the default stream).  Nothing here allocates, frees or synchronises: outputs
+ * and workspaces are caller-owned device memory, launches are asynchronous on
+ * the given stream.  Return value: MVX_OK or an MVX_ERR_* code; the message of
+ * the calling thread's last error is available from mvx_last_error().
+ *
+ * Each declaration names the function of the reference implementation
+ * (huskyth/PoseEstimation, package `mvn`) that it replaces.
+ */
+#ifndef MVX_H
+#define MVX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVX_VERSION 100 /* major*10000 + minor*100 + patch */
+
+enum mvx_status {
+    MVX_OK = 0,
+    MVX_ERR_INVALID_ARGUMENT = 1, /* null pointer, non-positive size, misaligned buffer */
+    MVX_ERR_HIP = 2,              /* a HIP runtime call or launch failed */
+    MVX_ERR_WORKSPACE = 3,        /* workspace smaller than the *_workspace_bytes() answer */
+    MVX_ERR_UNSUPPORTED = 4       /* shape outside what the kernels are built for */
+};
+
+/* View aggregation of mvx_unproject; mvn/utils/op.py:150-164 ("conf" and "conf_norm" are both MVX_AGG_CONF:
+ * the caller normalises the confidences, as mvn/models/triangulation.py:305-306 does). */
+enum mvx_aggregation {
+    MVX_AGG_SUM = 0,
+    MVX_AGG_CONF = 1,
+    MVX_AGG_MAX = 2,
+    MVX_AGG_SOFTMAX = 3
+};
+
+int mvx_version(void);
+const char* mvx_last_error(void);
+
+/*
+ * Soft-argmax of n_maps heatmaps of h x w.           Replaces mvn/utils/op.py:11-47 (integrate_tensor_2d),
+ * with the caller's `heatmaps * multiplier` (mvn/models/triangulation.py:190) folded in: each element is
+ * first rounded to float32(x * multiplier), exactly as the separate torch multiply does (pass 1.0f for none).
+ *   softmax != 0: p = softmax over h*w; coords = (sum p*col, sum p*row); heatmaps_out = p.
+ *   softmax == 0: p = max(x, 0);       coords = (sum p*col, sum p*row) / sum p; heatmaps_out = p (not normalised).
+ * heatmaps      [n_maps][h][w]
+ * coords        [n_maps][2]   (x, y) in heatmap pixels
+ * heatmaps_out  [n_maps][h][w] or NULL to skip the write (must not overlap `heatmaps`)
+ */
+int mvx_soft_argmax_2d(const float* heatmaps, int64_t n_maps, int h, int w, float multiplier, int softmax,
+                       float* coords, float* heatmaps_out, void* stream);
+
+/*
+ * Confidence-weighted DLT triangulation, one 3-D point per (frame, joint).
+ * Replaces mvn/utils/multiview.py:175-198 (triangulate_batch_of_points) and, per point,
+ * mvn/utils/multiview.py:143-172 (triangulate_point_from_multiple_views_linear_torch; its host LAPACK SVD
+ * becomes a 4x4 symmetric eigen-solve in float64 registers).
+ * proj    [n_frames][n_views][3][4]
+ * points  [n_frames][n_views][n_joints][2]
+ * conf    [n_frames][n_views][n_joints] or NULL (all ones)
+ * out     [n_frames][n_joints][3]
+ */
+int mvx_triangulate_dlt(const float* proj, const float* points, const float* conf, int64_t n_frames, int n_views,
+                        int n_joints, float* out, void* stream);
+
+/*
+ * The tensor glue of AlgebraicTriangulationNet.forward fused with the DLT.
+ * Replaces mvn/models/triangulation.py:199-200 (conf = conf / sum_views(conf) + 1e-5),
+ * :208-211 (keypoints scaled from heatmap to image pixels) and :217-220 (the triangulation call).
+ * points_hm      [n_frames][n_views][n_joints][2]  heatmap-pixel keypoints (output of mvx_soft_argmax_2d)
+ * conf_raw       [n_frames][n_views][n_joints]     confidences as the backbone emits them
+ * points_img_out [n_frames][n_views][n_joints][2]  x * scale_x, y * scale_y
+ * conf_norm_out  [n_frames][n_views][n_joints]
+ * out            [n_frames][n_joints][3]
+ */
+int mvx_algebraic_glue_dlt(const float* proj, const float* points_hm, const float* conf_raw, int64_t n_frames,
+                           int n_views, int n_joints, float scale_x, float scale_y, float* points_img_out,
+                           float* conf_norm_out, float* out, void* stream);
+
+/*
+ * Projects n_points 3-D points with one 3x4 matrix.  Replaces mvn/utils/multiview.py:91-112
+ * (project_3d_points_to_image_plane_without_distortion) for device tensors.
+ * out [n_points][2] if to_euclidean != 0 (divided by the third component), else [n_points][3].
+ */
+int mvx_project_points(const float* proj, const float* points, int64_t n_points, int to_euclidean, float* out,
+                       void* stream);
+
+/*
+ * Unprojects per-view feature maps into a voxel grid and aggregates the views.
+ * Replaces mvn/utils/op.py:99-166 (unproject_heatmaps).
+ * features   [n_frames][n_views][n_channels][h][w]
+ * proj       [n_frames][n_views][3][4]              projection to feature-map pixels
+ * coords     [n_frames][n_voxels][3]                world position of every voxel (n_voxels = X*Y*Z)
+ * vol_conf   [n_frames][n_views][n_channels]        MVX_AGG_CONF only, else may be NULL
+ * volumes    [n_frames][n_channels][n_voxels]
+ * workspace  mvx_unproject_workspace_bytes() bytes of device memory, 256-byte aligned (channel-last copy of
+ *            the feature maps)
+ */
+size_t mvx_unproject_workspace_bytes(int64_t n_frames, int n_views, int n_channels, int h, int w);
+int mvx_unproject(const float* features, const float* proj, const float* coords, const float* vol_conf,
+                  int64_t n_frames, int n_views, int n_channels, int h, int w, int64_t n_voxels, int aggregation,
+                  float* volumes, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Soft-argmax over voxel grids.
+ * coords_volume != NULL replaces mvn/utils/op.py:84-96 (integrate_tensor_3d_with_coordinates):
+ *   softmax != 0: p = softmax over the grid; out = sum p * coord;  softmax == 0: p = max(x,0), out = sum p * coord.
+ * coords_volume == NULL replaces mvn/utils/op.py:50-81 (integrate_tensor_3d): expectation of the voxel index
+ *   (x, y, z) instead; with softmax == 0 the result is divided by sum p.
+ * As in mvx_soft_argmax_2d every element is first rounded to float32(x * multiplier)
+ * (mvn/models/triangulation.py:399).
+ * volumes        [n_frames][n_volumes][sx][sy][sz]
+ * coords_volume  [n_frames][sx][sy][sz][3] or NULL
+ * out            [n_frames][n_volumes][3]
+ * volumes_out    [n_frames][n_volumes][sx][sy][sz] or NULL to skip the write
+ * workspace      mvx_soft_argmax_3d_workspace_bytes() bytes of device memory, 256-byte aligned
+ */
+size_t mvx_soft_argmax_3d_workspace_bytes(int64_t n_frames, int n_volumes, int sx, int sy, int sz);
+int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes, int sx,
+                       int sy, int sz, float multiplier, int softmax, float* out, float* volumes_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVX_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libmvx.so, the C ABI declared in include/mvx.h.
+
+The library is built in-tree (``make -C poseestimation_amd/csrc`` or ``__graft_entry__.build()``).
+There is no fallback: if the library is missing, or a tensor is not a float32 HIP device tensor, the
+calls below raise.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvx.so")
+
+MVX_OK, MVX_ERR_INVALID_ARGUMENT, MVX_ERR_HIP, MVX_ERR_WORKSPACE, MVX_ERR_UNSUPPORTED = range(5)
+AGG_SUM, AGG_CONF, AGG_MAX, AGG_SOFTMAX = range(4)
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers
+_i64, _int, _f32, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/mvx.h declares
+SIGNATURES = {
+    "mvx_version": (_int, []),
+    "mvx_last_error": (ctypes.c_char_p, []),
+    "mvx_soft_argmax_2d": (_int, [_vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp]),
+    "mvx_triangulate_dlt": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
+    "mvx_algebraic_glue_dlt": (_int, [_vp, _vp, _vp, _i64, _int, _int, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "mvx_project_points": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "mvx_unproject_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
+    "mvx_unproject": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _i64, _int, _vp, _vp, _sz, _vp]),
+    "mvx_soft_argmax_3d_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
+    "mvx_soft_argmax_3d": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class MvxError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libmvx.so once and declares every entry point; raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvxError(
+            "poseestimation_amd: %s is missing; build it with `make -C %s` (needs hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback for the triangulation kernels." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status == MVX_OK:
+        return
+    msg = load().mvx_last_error().decode("utf-8", "replace")
+    if status == MVX_ERR_INVALID_ARGUMENT:
+        raise ValueError("%s: %s" % (what, msg))
+    raise MvxError("%s failed (status %d): %s" % (what, status, msg))
+
+
+def device_f32(t, name):
+    """Returns `t` as a contiguous float32 tensor on its HIP device; raises for anything that is not on a GPU."""
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a torch tensor, got %s" % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise MvxError("%s is on %s: the mvx kernels run on a HIP device only (no CPU path)" % (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

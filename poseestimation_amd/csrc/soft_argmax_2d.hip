@@ -1,0 +1,231 @@
+// Soft-argmax over 2-D heatmaps (one workgroup of 256 threads per heatmap).
+//
+// HBM traffic per heatmap: one read of h*w floats, 8 bytes of coordinates, and (optionally) one write of
+// h*w floats.  The register kernel keeps the whole map in VGPRs between the max, the exp-sum and the
+// normalised write-back, so each element crosses HBM exactly once in each direction; the LDS kernel does
+// the same through a shared-memory tile for shapes the register kernel is not instantiated for; maps that
+// do not fit LDS are re-read from global memory (L2) per pass.
+//
+// Arithmetic: t = float32(x * multiplier); m = max t (exact); e = exp(t - m) in float32;
+// S = sum e, Sx = sum e*col, Sy = sum e*row in float64; x = Sx/S, y = Sy/S rounded once to float32.
+#include "mvx_common.h"
+
+namespace mvx {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+struct BlockReduce {
+    float m[kWaves];
+    double s[kWaves][3];
+};
+
+// Block-wide max of one float per thread; every thread gets the result.
+__device__ __forceinline__ float block_max(float v, BlockReduce& red) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red.m[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red.m[0], red.m[1]), fmaxf(red.m[2], red.m[3]));
+}
+
+// Block-wide sums of three doubles per thread; every thread gets the results.
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, BlockReduce& red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) {
+        red.s[threadIdx.x >> 6][0] = a;
+        red.s[threadIdx.x >> 6][1] = b;
+        red.s[threadIdx.x >> 6][2] = c;
+    }
+    __syncthreads();
+    a = (red.s[0][0] + red.s[1][0]) + (red.s[2][0] + red.s[3][0]);
+    b = (red.s[0][1] + red.s[1][1]) + (red.s[2][1] + red.s[3][1]);
+    c = (red.s[0][2] + red.s[1][2]) + (red.s[2][2] + red.s[3][2]);
+}
+
+// Adds the four elements of one float4 (same row, columns col..col+3) to the float64 sums.
+__device__ __forceinline__ void accumulate4(const float4& e, int row, int col, double& s, double& sx, double& sy) {
+    const double e0 = e.x, e1 = e.y, e2 = e.z, e3 = e.w;
+    const double s4 = (e0 + e1) + (e2 + e3);
+    s += s4;
+    sy = fma(s4, static_cast<double>(row), sy);
+    sx = fma(s4, static_cast<double>(col), sx);
+    sx += fma(3.0, e3, fma(2.0, e2, e1));
+}
+
+// h*w == 256*4*NV and w % 4 == 0: the map lives in NV float4 registers per thread.
+template <int NV>
+__global__ __launch_bounds__(kThreads) void soft_argmax_2d_reg(const float* __restrict__ hm, int w, float mult,
+                                                                int softmax, float* __restrict__ coords,
+                                                                float* __restrict__ out) {
+    __shared__ BlockReduce red;
+    const int tid = threadIdx.x;
+    const size_t map = blockIdx.x;
+    constexpr int HW = kThreads * 4 * NV;
+    const float4* src = reinterpret_cast<const float4*>(hm + map * HW);
+
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = src[k * kThreads + tid];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k].x *= mult;
+        v[k].y *= mult;
+        v[k].z *= mult;
+        v[k].w *= mult;
+    }
+
+    float m = 0.0f;
+    if (softmax) {
+        m = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+#pragma unroll
+        for (int k = 1; k < NV; ++k) m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+        m = block_max(m, red);
+    }
+
+    // position of this thread's first float4 and the (uniform) step between its float4s
+    int row = (tid * 4) / w, col = (tid * 4) % w;
+    const int row_step = (kThreads * 4) / w, col_step = (kThreads * 4) % w;
+    double s = 0.0, sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (softmax) {
+            v[k].x = exp_neg(v[k].x - m);
+            v[k].y = exp_neg(v[k].y - m);
+            v[k].z = exp_neg(v[k].z - m);
+            v[k].w = exp_neg(v[k].w - m);
+        } else {
+            v[k].x = fmaxf(v[k].x, 0.0f);
+            v[k].y = fmaxf(v[k].y, 0.0f);
+            v[k].z = fmaxf(v[k].z, 0.0f);
+            v[k].w = fmaxf(v[k].w, 0.0f);
+        }
+        accumulate4(v[k], row, col, s, sx, sy);
+        row += row_step;
+        col += col_step;
+        if (col >= w) {
+            col -= w;
+            row += 1;
+        }
+    }
+    block_sum3(s, sx, sy, red);
+
+    if (tid == 0) {
+        coords[map * 2 + 0] = static_cast<float>(sx / s);
+        coords[map * 2 + 1] = static_cast<float>(sy / s);
+    }
+    if (out != nullptr) {
+        const float inv = softmax ? static_cast<float>(1.0 / s) : 1.0f;
+        float4* dst = reinterpret_cast<float4*>(out + map * HW);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            float4 p = v[k];
+            p.x *= inv;
+            p.y *= inv;
+            p.z *= inv;
+            p.w *= inv;
+            dst[k * kThreads + tid] = p;
+        }
+    }
+}
+
+// Any h, w.  STAGED: the scaled map is staged once in dynamic LDS and the later passes read the tile;
+// otherwise every pass re-reads global memory.
+template <bool STAGED>
+__global__ __launch_bounds__(kThreads) void soft_argmax_2d_any(const float* __restrict__ hm, int h, int w, float mult,
+                                                                int softmax, float* __restrict__ coords,
+                                                                float* __restrict__ out) {
+    extern __shared__ __align__(16) float tile[];
+    __shared__ BlockReduce red;
+    const int tid = threadIdx.x;
+    const size_t map = blockIdx.x;
+    const int hw = h * w;
+    const float* src = hm + map * static_cast<size_t>(hw);
+
+    float m = -INFINITY;
+    for (int i = tid; i < hw; i += kThreads) {
+        const float t = src[i] * mult;
+        if (STAGED) tile[i] = t;
+        m = fmaxf(m, t);
+    }
+    if (softmax) {
+        m = block_max(m, red);  // also orders the tile writes before the reads below
+    } else {
+        m = 0.0f;
+        __syncthreads();
+    }
+
+    double s = 0.0, sx = 0.0, sy = 0.0;
+    for (int i = tid; i < hw; i += kThreads) {
+        const float t = STAGED ? tile[i] : src[i] * mult;
+        const float e = softmax ? exp_neg(t - m) : fmaxf(t, 0.0f);
+        if (STAGED) tile[i] = e;
+        const int row = i / w, col = i - row * w;
+        const double ed = e;
+        s += ed;
+        sx = fma(ed, static_cast<double>(col), sx);
+        sy = fma(ed, static_cast<double>(row), sy);
+    }
+    block_sum3(s, sx, sy, red);
+
+    if (tid == 0) {
+        coords[map * 2 + 0] = static_cast<float>(sx / s);
+        coords[map * 2 + 1] = static_cast<float>(sy / s);
+    }
+    if (out != nullptr) {
+        const float inv = softmax ? static_cast<float>(1.0 / s) : 1.0f;
+        float* dst = out + map * static_cast<size_t>(hw);
+        for (int i = tid; i < hw; i += kThreads) {
+            float e;
+            if (STAGED) {
+                e = tile[i];
+            } else {
+                const float t = src[i] * mult;
+                e = softmax ? exp_neg(t - m) : fmaxf(t, 0.0f);
+            }
+            dst[i] = e * inv;
+        }
+    }
+}
+
+}  // namespace
+
+}  // namespace mvx
+
+extern "C" int mvx_soft_argmax_2d(const float* heatmaps, int64_t n_maps, int h, int w, float multiplier, int softmax,
+                                  float* coords, float* heatmaps_out, void* stream) {
+    using namespace mvx;
+    MVX_REQUIRE(n_maps >= 0 && h > 0 && w > 0, MVX_ERR_INVALID_ARGUMENT,
+                "mvx_soft_argmax_2d: bad shape n_maps=%lld h=%d w=%d", (long long)n_maps, h, w);
+    if (n_maps == 0) return MVX_OK;
+    MVX_REQUIRE(heatmaps != nullptr && coords != nullptr, MVX_ERR_INVALID_ARGUMENT,
+                "mvx_soft_argmax_2d: null heatmaps or coords pointer");
+    MVX_REQUIRE(n_maps <= 0x7fffffffLL && static_cast<int64_t>(h) * w <= (1 << 24), MVX_ERR_UNSUPPORTED,
+                "mvx_soft_argmax_2d: n_maps=%lld or h*w=%lld beyond the launch limits", (long long)n_maps,
+                (long long)h * w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(static_cast<unsigned>(n_maps)), block(kThreads);
+    const int hw = h * w;
+    const bool vec_ok = (w % 4 == 0) && aligned16(heatmaps) && (heatmaps_out == nullptr || aligned16(heatmaps_out));
+    if (vec_ok && hw == kThreads * 4 * 9) {  // 96 x 96
+        hipLaunchKernelGGL(soft_argmax_2d_reg<9>, grid, block, 0, st, heatmaps, w, multiplier, softmax, coords,
+                           heatmaps_out);
+    } else if (vec_ok && hw == kThreads * 4 * 4) {  // 64 x 64
+        hipLaunchKernelGGL(soft_argmax_2d_reg<4>, grid, block, 0, st, heatmaps, w, multiplier, softmax, coords,
+                           heatmaps_out);
+    } else if (vec_ok && hw == kThreads * 4 * 16) {  // 128 x 128
+        hipLaunchKernelGGL(soft_argmax_2d_reg<16>, grid, block, 0, st, heatmaps, w, multiplier, softmax, coords,
+                           heatmaps_out);
+    } else if (static_cast<size_t>(hw) * sizeof(float) <= 64 * 1024) {
+        hipLaunchKernelGGL(soft_argmax_2d_any<true>, grid, block, static_cast<size_t>(hw) * sizeof(float), st,
+                           heatmaps, h, w, multiplier, softmax, coords, heatmaps_out);
+    } else {
+        hipLaunchKernelGGL(soft_argmax_2d_any<false>, grid, block, 0, st, heatmaps, h, w, multiplier, softmax,
+                           coords, heatmaps_out);
+    }
+    MVX_CHECK_LAUNCH("mvx_soft_argmax_2d");
+    return MVX_OK;
+}

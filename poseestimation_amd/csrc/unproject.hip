@@ -1,0 +1,350 @@
+// Unprojection of per-view feature maps into a voxel grid with view aggregation.
+//
+// Step 1 copies the feature maps of a few frames from [view][channel][h][w] to channel-last
+// [view][h][w][channel] (channels padded to a multiple of 4), so that the C channels of one bilinear tap are
+// one contiguous C*4-byte run (a full 128-byte line for C = 32).  The copy of a chunk of frames is consumed
+// straight away by step 2 and is small enough to stay in L2 / Infinity Cache.
+//
+// Step 2, tile kernel (C = 32): a workgroup owns 128 consecutive voxels of one frame.
+//   phase A  one thread per voxel projects it into every view and leaves the four bilinear weights (zero for
+//            taps outside the map and for voxels behind the camera) and the tap address in LDS;
+//   phase B  8 lanes per voxel, 4 channels per lane: four 16-byte loads per view fetch the 2x2 taps (each
+//            wave-instruction consumes whole 128-byte lines), the view aggregation runs in registers
+//            (sum / confidence-weighted / max / online softmax over views), results go to an LDS tile
+//            [channel][voxel] (XOR-swizzled so both sides are conflict-free);
+//   phase C  the tile is stored with 16 bytes per lane: 512 contiguous bytes per channel.
+// The per-view volumes of the reference (V x C x N floats per frame) are never materialised.
+// Workgroup ids are remapped so that each XCD works through consecutive tiles of the same frame and its L2
+// holds just that frame's feature maps.
+//
+// Step 2, generic kernel (any C, V, grid): one lane per (voxel, 4 channels), no LDS, direct stores.
+//
+// HBM traffic per frame: V*C*h*w*4 (features) + N*12 (coordinates) + C*N*4 (volume written).
+#include "mvx_common.h"
+
+namespace mvx {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunkFrames = 8;  // frames per channel-last copy + sampling round (one per XCD)
+
+struct Tap {
+    float w00, w01, w10, w11;  // weights of (yb, xb), (yb, xb+1), (yb+1, xb), (yb+1, xb+1)
+    unsigned pixel;            // yb * W + xb, always inside the map
+};
+
+// Projects one voxel with P (3x4, row-major), converts to the sampling position exactly as the reference's
+// float32 sequence does -- x/z, then gx = 2(x/H - 0.5), gy = 2(y/W - 0.5) (H for x and W for y), then
+// grid_sample(align_corners=True): ix = (gx + 1)/2 * (W - 1), iy = (gy + 1)/2 * (H - 1) -- and returns
+// the bilinear taps with zero padding.  A voxel with z <= 0 gets all-zero weights.
+__device__ __forceinline__ Tap project_tap(const float* __restrict__ P, float cx, float cy, float cz, int H, int W) {
+    const float u = fmaf(cx, P[0], fmaf(cy, P[1], fmaf(cz, P[2], P[3])));
+    const float v = fmaf(cx, P[4], fmaf(cy, P[5], fmaf(cz, P[6], P[7])));
+    const float z = fmaf(cx, P[8], fmaf(cy, P[9], fmaf(cz, P[10], P[11])));
+    const bool behind = z <= 0.0f;
+    const float zz = (z == 0.0f) ? 1.0f : z;
+    const float x = u / zz, y = v / zz;
+    const float gx = 2.0f * (x / static_cast<float>(H) - 0.5f);
+    const float gy = 2.0f * (y / static_cast<float>(W) - 0.5f);
+    const float ix = ((gx + 1.0f) / 2.0f) * static_cast<float>(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * static_cast<float>(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx0 = (x0f + 1.0f) - ix, wx1 = ix - x0f;
+    const float wy0 = (y0f + 1.0f) - iy, wy1 = iy - y0f;
+    // clamp before the conversion so that far-away or non-finite positions become "outside"
+    const int x0 = static_cast<int>(fminf(fmaxf(x0f, -2.0f), static_cast<float>(W)));
+    const int y0 = static_cast<int>(fminf(fmaxf(y0f, -2.0f), static_cast<float>(H)));
+    const bool finite = (ix - ix == 0.0f) && (iy - iy == 0.0f) && !behind;
+    const bool vx0 = finite && x0 >= 0 && x0 <= W - 1, vx1 = finite && x0 + 1 >= 0 && x0 + 1 <= W - 1;
+    const bool vy0 = finite && y0 >= 0 && y0 <= H - 1, vy1 = finite && y0 + 1 >= 0 && y0 + 1 <= H - 1;
+    const int xb = min(max(x0, 0), W - 2), yb = min(max(y0, 0), H - 2);
+    // column xb holds tap x0 (if x0 == xb) or tap x0+1 (if x0 + 1 == xb, i.e. x0 == -1); likewise xb+1
+    const float cxa = (vx0 && x0 == xb) ? wx0 : ((vx1 && x0 + 1 == xb) ? wx1 : 0.0f);
+    const float cxb = (vx1 && x0 == xb) ? wx1 : ((vx0 && x0 == xb + 1) ? wx0 : 0.0f);
+    const float cya = (vy0 && y0 == yb) ? wy0 : ((vy1 && y0 + 1 == yb) ? wy1 : 0.0f);
+    const float cyb = (vy1 && y0 == yb) ? wy1 : ((vy0 && y0 == yb + 1) ? wy0 : 0.0f);
+    Tap t;
+    t.w00 = cxa * cya;
+    t.w01 = cxb * cya;
+    t.w10 = cxa * cyb;
+    t.w11 = cxb * cyb;
+    t.pixel = static_cast<unsigned>(yb * W + xb);
+    return t;
+}
+
+// Aggregation over views of four channels at a time.
+template <int AGG>
+struct Aggregator {
+    float a[4], num[4], den[4];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = (AGG == MVX_AGG_MAX || AGG == MVX_AGG_SOFTMAX) ? -INFINITY : 0.0f;
+            num[k] = 0.0f;
+            den[k] = 0.0f;
+        }
+    }
+    __device__ __forceinline__ void add(const float (&val)[4], const float (&conf)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (AGG == MVX_AGG_SUM) {
+                a[k] += val[k];
+            } else if (AGG == MVX_AGG_CONF) {
+                a[k] = fmaf(val[k], conf[k], a[k]);
+            } else if (AGG == MVX_AGG_MAX) {
+                a[k] = fmaxf(a[k], val[k]);
+            } else {
+                // online softmax over views with one exp per value: a = running max,
+                // num = sum val*exp(val - a), den = sum exp(val - a)
+                const float d = val[k] - a[k];
+                const float r = exp_neg(-fabsf(d));
+                const bool up = d > 0.0f;
+                const float keep = up ? r : 1.0f;  // rescale of what is already summed
+                const float e = up ? 1.0f : r;     // weight of the new value
+                den[k] = fmaf(den[k], keep, e);
+                num[k] = fmaf(num[k], keep, e * val[k]);
+                a[k] = up ? val[k] : a[k];
+            }
+        }
+    }
+    __device__ __forceinline__ float result(int k) const { return AGG == MVX_AGG_SOFTMAX ? num[k] / den[k] : a[k]; }
+};
+
+__device__ __forceinline__ void sample4(const float* __restrict__ img, const Tap& t, int W, int Cp, int q,
+                                        float (&val)[4]) {
+    const float* p = img + static_cast<size_t>(t.pixel) * Cp + q * 4;
+    const float4 f00 = *reinterpret_cast<const float4*>(p);
+    const float4 f01 = *reinterpret_cast<const float4*>(p + Cp);
+    const float4 f10 = *reinterpret_cast<const float4*>(p + static_cast<size_t>(W) * Cp);
+    const float4 f11 = *reinterpret_cast<const float4*>(p + static_cast<size_t>(W) * Cp + Cp);
+    val[0] = fmaf(f11.x, t.w11, fmaf(f10.x, t.w10, fmaf(f01.x, t.w01, f00.x * t.w00)));
+    val[1] = fmaf(f11.y, t.w11, fmaf(f10.y, t.w10, fmaf(f01.y, t.w01, f00.y * t.w00)));
+    val[2] = fmaf(f11.z, t.w11, fmaf(f10.z, t.w10, fmaf(f01.z, t.w01, f00.z * t.w00)));
+    val[3] = fmaf(f11.w, t.w11, fmaf(f10.w, t.w10, fmaf(f01.w, t.w01, f00.w * t.w00)));
+}
+
+// [n][C][HW] -> [n][HW][Cp], Cp = C rounded up to 4 (pad = 0).  64-pixel x 32-channel tiles through LDS.
+__global__ __launch_bounds__(kThreads) void to_channel_last(const float* __restrict__ src, int C, int Cp, int HW,
+                                                             int p_tiles, int c_tiles, float* __restrict__ dst) {
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    unsigned id = blockIdx.x;
+    const int pt = id % p_tiles;
+    id /= p_tiles;
+    const int ct = id % c_tiles;
+    const size_t n = id / c_tiles;
+    const int p0 = pt * 64, c0 = ct * 32;
+    {
+        const int tx = tid & 63, ty = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + ty + 4 * i, px = p0 + tx;
+            tile[ty + 4 * i][tx] = (c < C && px < HW) ? src[(n * C + c) * HW + px] : 0.0f;
+        }
+    }
+    __syncthreads();
+    {
+        const int cx = tid & 31, py = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int px = p0 + py + 8 * i, c = c0 + cx;
+            if (px < HW && c < Cp) dst[(n * HW + px) * Cp + c] = tile[cx][py + 8 * i];
+        }
+    }
+}
+
+// One lane per (voxel, channel quad).  feat_cl: channel-last maps of frames [f0, f0+nf).
+template <int AGG>
+__global__ __launch_bounds__(kThreads) void unproject_generic(const float* __restrict__ feat_cl,
+                                                              const float* __restrict__ proj,
+                                                              const float* __restrict__ coord,
+                                                              const float* __restrict__ vconf, int64_t n_items,
+                                                              int V, int C, int Cp, int H, int W, int64_t n_vox,
+                                                              float* __restrict__ vol) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (idx >= n_items) return;
+    const int Cq = Cp >> 2;
+    const int q = static_cast<int>(idx % Cq);
+    const int64_t bn = idx / Cq;
+    const int64_t b = bn / n_vox, n = bn - b * n_vox;
+    const float* cp = coord + (b * n_vox + n) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    Aggregator<AGG> agg;
+    agg.init();
+    for (int v = 0; v < V; ++v) {
+        const Tap t = project_tap(proj + (b * V + v) * 12, cx, cy, cz, H, W);
+        float val[4], conf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        sample4(feat_cl + (b * V + v) * static_cast<size_t>(H) * W * Cp, t, W, Cp, q, val);
+        if (AGG == MVX_AGG_CONF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) conf[k] = (q * 4 + k < C) ? vconf[(b * V + v) * C + q * 4 + k] : 0.0f;
+        }
+        agg.add(val, conf);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = q * 4 + k;
+        if (c < C) vol[(b * C + c) * n_vox + n] = agg.result(k);
+    }
+}
+
+// C = 32, TILE voxels per workgroup (n_vox % TILE == 0), V <= kTileMaxViews.
+constexpr int kTile = 128;
+constexpr int kTileMaxViews = 16;
+
+template <int AGG>
+__global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __restrict__ feat_cl,
+                                                             const float* __restrict__ proj,
+                                                             const float* __restrict__ coord,
+                                                             const float* __restrict__ vconf, int V, int H, int W,
+                                                             int64_t n_vox, int tiles_per_frame,
+                                                             float* __restrict__ vol) {
+    constexpr int C = 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* out_t = reinterpret_cast<float*>(smem);                                 // [32][kTile], swizzled
+    float4* wts = reinterpret_cast<float4*>(smem + C * kTile * sizeof(float));     // [V][kTile]
+    unsigned* pix = reinterpret_cast<unsigned*>(wts + static_cast<size_t>(V) * kTile);  // [V][kTile]
+
+    const int tid = threadIdx.x;
+    const unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t b = work / tiles_per_frame;
+    const int64_t n0 = static_cast<int64_t>(work % tiles_per_frame) * kTile;
+    const size_t img_stride = static_cast<size_t>(H) * W * C;
+
+    // phase A: taps of every (view, voxel) of the tile
+    for (int i = tid; i < V * kTile; i += kThreads) {
+        const int v = i / kTile, t = i - v * kTile;
+        const float* cp = coord + (b * n_vox + n0 + t) * 3;
+        const Tap tap = project_tap(proj + (b * V + v) * 12, cp[0], cp[1], cp[2], H, W);
+        wts[i] = make_float4(tap.w00, tap.w01, tap.w10, tap.w11);
+        pix[i] = tap.pixel;
+    }
+    __syncthreads();
+
+    // phase B: 8 lanes per voxel, 4 channels per lane
+    const int q = tid & 7;
+    const float* fb = feat_cl + b * V * img_stride;
+#pragma unroll 2
+    for (int step = 0; step < kTile / 32; ++step) {
+        const int t = step * 32 + (tid >> 3);
+        Aggregator<AGG> agg;
+        agg.init();
+        for (int v = 0; v < V; ++v) {
+            const float4 w4 = wts[v * kTile + t];
+            Tap tap;
+            tap.w00 = w4.x;
+            tap.w01 = w4.y;
+            tap.w10 = w4.z;
+            tap.w11 = w4.w;
+            tap.pixel = pix[v * kTile + t];
+            float val[4], conf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            sample4(fb + v * img_stride, tap, W, C, q, val);
+            if (AGG == MVX_AGG_CONF) {
+                const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * V + v) * C + q * 4);
+                conf[0] = c4.x;
+                conf[1] = c4.y;
+                conf[2] = c4.z;
+                conf[3] = c4.w;
+            }
+            agg.add(val, conf);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = agg.result(k);
+    }
+    __syncthreads();
+
+    // phase C: 16 bytes per lane, 512 contiguous bytes per channel
+#pragma unroll
+    for (int i = 0; i < (C * kTile / 4) / kThreads; ++i) {
+        const int flat = i * kThreads + tid;
+        const int c = flat / (kTile / 4), grp = flat % (kTile / 4);
+        const float4 r = *reinterpret_cast<const float4*>(out_t + c * kTile + ((grp ^ ((c >> 2) & 7)) << 2));
+        *reinterpret_cast<float4*>(vol + (b * C + c) * n_vox + n0 + grp * 4) = r;
+    }
+}
+
+}  // namespace
+
+}  // namespace mvx
+
+extern "C" size_t mvx_unproject_workspace_bytes(int64_t n_frames, int n_views, int n_channels, int h, int w) {
+    if (n_frames <= 0 || n_views <= 0 || n_channels <= 0 || h <= 0 || w <= 0) return 0;
+    const int64_t frames = n_frames < mvx::kChunkFrames ? n_frames : mvx::kChunkFrames;
+    const int64_t cp = (n_channels + 3) / 4 * 4;
+    return static_cast<size_t>(frames) * n_views * h * w * cp * sizeof(float);
+}
+
+extern "C" int mvx_unproject(const float* features, const float* proj, const float* coords, const float* vol_conf,
+                             int64_t n_frames, int n_views, int n_channels, int h, int w, int64_t n_voxels,
+                             int aggregation, float* volumes, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace mvx;
+    MVX_REQUIRE(n_frames >= 0 && n_views > 0 && n_channels > 0 && h >= 2 && w >= 2 && n_voxels >= 0,
+                MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: bad shape n_frames=%lld n_views=%d n_channels=%d h=%d w=%d n_voxels=%lld",
+                (long long)n_frames, n_views, n_channels, h, w, (long long)n_voxels);
+    MVX_REQUIRE(aggregation >= MVX_AGG_SUM && aggregation <= MVX_AGG_SOFTMAX, MVX_ERR_INVALID_ARGUMENT,
+                "mvx_unproject: unknown aggregation %d", aggregation);
+    if (n_frames == 0 || n_voxels == 0) return MVX_OK;
+    MVX_REQUIRE(features != nullptr && proj != nullptr && coords != nullptr && volumes != nullptr &&
+                    workspace != nullptr,
+                MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: null pointer argument");
+    MVX_REQUIRE(aggregation != MVX_AGG_CONF || vol_conf != nullptr, MVX_ERR_INVALID_ARGUMENT,
+                "mvx_unproject: confidence aggregation needs vol_conf");
+    MVX_REQUIRE(workspace_bytes >= mvx_unproject_workspace_bytes(n_frames, n_views, n_channels, h, w),
+                MVX_ERR_WORKSPACE, "mvx_unproject: workspace of %zu bytes is too small", workspace_bytes);
+    MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: workspace must be 16-byte aligned");
+    const int C = n_channels, Cp = (C + 3) / 4 * 4, V = n_views, HW = h * w;
+    MVX_REQUIRE(static_cast<int64_t>(h) * w * Cp < (1LL << 31), MVX_ERR_UNSUPPORTED,
+                "mvx_unproject: one feature map exceeds 2^31 elements");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* feat_cl = static_cast<float*>(workspace);
+    const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
+    const bool tiled = (C == 32) && (V <= kTileMaxViews) && (n_voxels % kTile == 0) && aligned16(volumes) &&
+                       (aggregation != MVX_AGG_CONF || aligned16(vol_conf));
+    const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V) * kTile * 20;
+
+    for (int64_t f0 = 0; f0 < n_frames; f0 += kChunkFrames) {
+        const int64_t nf = (n_frames - f0 < kChunkFrames) ? n_frames - f0 : kChunkFrames;
+        const int64_t t_blocks = nf * V * static_cast<int64_t>(p_tiles) * c_tiles;
+        MVX_REQUIRE(t_blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: feature maps too large");
+        hipLaunchKernelGGL(to_channel_last, dim3(static_cast<unsigned>(t_blocks)), dim3(kThreads), 0, st,
+                           features + f0 * V * C * HW, C, Cp, HW, p_tiles, c_tiles, feat_cl);
+        MVX_CHECK_LAUNCH("mvx_unproject (channel-last copy)");
+        const float* pj = proj + f0 * V * 12;
+        const float* cd = coords + f0 * n_voxels * 3;
+        const float* vc = vol_conf != nullptr ? vol_conf + f0 * V * C : nullptr;
+        float* vo = volumes + f0 * C * n_voxels;
+        if (tiled) {
+            const int64_t tiles = n_voxels / kTile;
+            MVX_REQUIRE(nf * tiles <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: voxel grid too large");
+            const dim3 grid(static_cast<unsigned>(nf * tiles));
+#define MVX_LAUNCH_TILE(AGG)                                                                                       \
+    hipLaunchKernelGGL(unproject_tile32<AGG>, grid, dim3(kThreads), smem, st, feat_cl, pj, cd, vc, V, h, w, n_voxels, \
+                       static_cast<int>(tiles), vo)
+            switch (aggregation) {
+                case MVX_AGG_SUM: MVX_LAUNCH_TILE(MVX_AGG_SUM); break;
+                case MVX_AGG_CONF: MVX_LAUNCH_TILE(MVX_AGG_CONF); break;
+                case MVX_AGG_MAX: MVX_LAUNCH_TILE(MVX_AGG_MAX); break;
+                default: MVX_LAUNCH_TILE(MVX_AGG_SOFTMAX); break;
+            }
+#undef MVX_LAUNCH_TILE
+        } else {
+            const int64_t n_items = nf * n_voxels * (Cp / 4);
+            const int64_t blocks = (n_items + kThreads - 1) / kThreads;
+            MVX_REQUIRE(blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: voxel grid too large");
+            const dim3 grid(static_cast<unsigned>(blocks));
+#define MVX_LAUNCH_GENERIC(AGG)                                                                                  \
+    hipLaunchKernelGGL(unproject_generic<AGG>, grid, dim3(kThreads), 0, st, feat_cl, pj, cd, vc, n_items, V, C, Cp, h, \
+                       w, n_voxels, vo)
+            switch (aggregation) {
+                case MVX_AGG_SUM: MVX_LAUNCH_GENERIC(MVX_AGG_SUM); break;
+                case MVX_AGG_CONF: MVX_LAUNCH_GENERIC(MVX_AGG_CONF); break;
+                case MVX_AGG_MAX: MVX_LAUNCH_GENERIC(MVX_AGG_MAX); break;
+                default: MVX_LAUNCH_GENERIC(MVX_AGG_SOFTMAX); break;
+            }
+#undef MVX_LAUNCH_GENERIC
+        }
+        MVX_CHECK_LAUNCH("mvx_unproject (sampling)");
+    }
+    return MVX_OK;
+}

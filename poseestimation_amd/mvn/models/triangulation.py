@@ -1,0 +1,228 @@
+"""AlgebraicTriangulationNet and VolumetricTriangulationNet with the reference's constructor and
+`forward(images, proj_matricies, batch)` signatures and return tuples
+(reference: mvn/models/triangulation.py:151-236 and :240-403), running the triangulation maths on the
+mvx HIP kernels.
+
+The heatmap backbone and the V2V volume network are not part of this package: they are taken from the
+reference's own `mvn.models.pose_resnet` / `mvn.models.v2v` when that tree is importable, or passed in
+(`backbone=`, `volume_net=`).  State-dict keys (`backbone.*`, `process_features.*`, `volume_net.*`) are the
+reference's, so its checkpoints load with strict=True.  Forward-only: the triangulation ops record no
+autograd graph (the reference's algebraic path is not differentiable either, mvn/utils/multiview.py:166).
+"""
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+from torch import nn
+
+from poseestimation_amd import _cabi
+from poseestimation_amd.mvn.utils import op, volumetric
+
+
+def _reference_backbone(backbone_config, device):
+    try:
+        from mvn.models import pose_resnet  # the reference's tree, if it is on sys.path
+    except ImportError as e:
+        raise ImportError(
+            "no backbone given and the reference's mvn.models.pose_resnet is not importable; put the reference "
+            "checkout on sys.path or pass backbone=<nn.Module returning (heatmaps, features, alg_conf, vol_conf)>"
+        ) from e
+    return pose_resnet.get_pose_net(backbone_config, device=device)
+
+
+def _reference_volume_net(in_channels, out_channels):
+    try:
+        from mvn.models.v2v import V2VModel
+    except ImportError as e:
+        raise ImportError(
+            "no volume_net given and the reference's mvn.models.v2v is not importable; put the reference checkout "
+            "on sys.path or pass volume_net=<nn.Module mapping (B,32,S,S,S) to (B,J,S,S,S)>") from e
+    return V2VModel(in_channels, out_channels)
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+class AlgebraicTriangulationNet(nn.Module):
+    def __init__(self, config, device='cuda:0', backbone=None):
+        super().__init__()
+        self.use_confidences = config.model.use_confidences
+        # the reference rewrites these backbone flags in place (triangulation.py:157-161)
+        config.model.backbone.alg_confidences = False
+        config.model.backbone.vol_confidences = False
+        if self.use_confidences:
+            config.model.backbone.alg_confidences = True
+        self.backbone = backbone if backbone is not None else _reference_backbone(config.model.backbone, device)
+        self.heatmap_softmax = config.model.heatmap_softmax
+        self.heatmap_multiplier = config.model.heatmap_multiplier
+
+    def triangulate_from_heatmaps(self, heatmaps, alg_confidences, proj_matricies, image_shape):
+        """Everything after the backbone: soft-argmax (multiplier folded in), confidence normalisation,
+        keypoint upscale and DLT; two kernel launches.
+
+        heatmaps (B, V, J, h, w) raw backbone output; alg_confidences (B, V, J); proj_matricies (B, V, 3, 4)
+        for image pixels; image_shape (H, W).  Returns (keypoints_3d (B, J, 3), keypoints_2d (B, V, J, 2) in
+        image pixels, normalised heatmaps (B, V, J, h, w), confidences (B, V, J))."""
+        hm = _cabi.device_f32(heatmaps, "heatmaps")
+        b, v, j, h, w = hm.shape
+        kp_hm, hm_norm = op.integrate_tensor_2d(hm.view(b * v, j, h, w), self.heatmap_softmax,
+                                                multiplier=self.heatmap_multiplier)
+        conf = _cabi.device_f32(alg_confidences, "alg_confidences").reshape(b, v, j)
+        proj = _cabi.device_f32(proj_matricies, "proj_matricies")
+        if tuple(proj.shape) != (b, v, 3, 4):
+            raise ValueError("proj_matricies must have shape %s, got %s" % ((b, v, 3, 4), tuple(proj.shape)))
+        kp_img = torch.empty((b, v, j, 2), dtype=torch.float32, device=hm.device)
+        conf_norm = torch.empty((b, v, j), dtype=torch.float32, device=hm.device)
+        kp3d = torch.zeros((b, j, 3), dtype=torch.float32, device=hm.device)
+        with torch.cuda.device(hm.device):
+            st = _cabi.load().mvx_algebraic_glue_dlt(
+                _cabi.ptr(proj), _cabi.ptr(kp_hm), _cabi.ptr(conf), b, v, j, float(image_shape[1] / w),
+                float(image_shape[0] / h), _cabi.ptr(kp_img), _cabi.ptr(conf_norm), _cabi.ptr(kp3d),
+                _cabi.stream(hm.device))
+        _cabi.check(st, "mvx_algebraic_glue_dlt")
+        return kp3d, kp_img, hm_norm.view(b, v, j, h, w), conf_norm
+
+    def forward(self, images, proj_matricies, batch):
+        device = images.device
+        batch_size, n_views = images.shape[:2]
+        images = images.view(-1, *images.shape[2:])
+
+        _sync(device)
+        if self.use_confidences:
+            heatmaps, _, alg_confidences, _ = self.backbone(images)
+        else:
+            heatmaps, _, _, _ = self.backbone(images)
+            alg_confidences = torch.ones(batch_size * n_views, heatmaps.shape[1], dtype=torch.float32, device=device)
+        _sync(device)
+        t1 = time.time()
+
+        image_shape = tuple(images.shape[2:])
+        heatmaps = heatmaps.view(batch_size, n_views, *heatmaps.shape[1:])
+        alg_confidences = alg_confidences.view(batch_size, n_views, *alg_confidences.shape[1:])
+        with torch.no_grad():
+            keypoints_3d, keypoints_2d, heatmaps, alg_confidences = self.triangulate_from_heatmaps(
+                heatmaps, alg_confidences, proj_matricies, image_shape)
+        _sync(device)
+        t2 = time.time()
+        # same 6-tuple as the reference, including its two wall-clock stamps (triangulation.py:236)
+        return keypoints_3d, keypoints_2d, heatmaps, alg_confidences, t1, t2
+
+
+class VolumetricTriangulationNet(nn.Module):
+    def __init__(self, config, device='cuda:0', backbone=None, volume_net=None):
+        super().__init__()
+        self.num_joints = config.model.backbone.num_joints
+        self.volume_aggregation_method = config.model.volume_aggregation_method
+        self.volume_softmax = config.model.volume_softmax
+        self.volume_multiplier = config.model.volume_multiplier
+        self.volume_size = config.model.volume_size
+        self.cuboid_side = config.model.cuboid_side
+        self.kind = config.model.kind
+        self.use_gt_pelvis = config.model.use_gt_pelvis
+        self.heatmap_softmax = config.model.heatmap_softmax
+        self.heatmap_multiplier = config.model.heatmap_multiplier
+        self.transfer_cmu_to_human36m = getattr(config.model, "transfer_cmu_to_human36m", False)
+
+        config.model.backbone.alg_confidences = False
+        config.model.backbone.vol_confidences = False
+        if self.volume_aggregation_method.startswith('conf'):
+            config.model.backbone.vol_confidences = True
+        self.backbone = backbone if backbone is not None else _reference_backbone(config.model.backbone, device)
+        final_layer = getattr(self.backbone, "final_layer", None)
+        if final_layer is not None:
+            for p in final_layer.parameters():
+                p.requires_grad = False
+        self.process_features = nn.Sequential(nn.Conv2d(256, 32, 1))
+        self.volume_net = volume_net if volume_net is not None else _reference_volume_net(32, self.num_joints)
+
+    def _base_points(self, batch, batch_size):
+        """(B, 3) float64 host array: pelvis (joint 6) for "mpii", mid-hip (joints 11, 12) for "coco"."""
+        key = 'keypoints_3d' if self.use_gt_pelvis else 'pred_keypoints_3d'
+        pts = np.zeros((batch_size, 3), dtype=np.float64)
+        for i in range(batch_size):
+            kp = np.asarray(batch[key][i])
+            if self.kind == "coco":
+                pts[i] = (kp[11, :3] + kp[12, :3]) / 2
+            elif self.kind == "mpii":
+                pts[i] = kp[6, :3]
+            else:
+                raise ValueError("unknown skeleton kind: %s" % (self.kind,))
+        return pts
+
+    def build_coord_volumes(self, base_points_np, device):
+        """Coordinate volumes (B, S, S, S, 3), float32, index order [x, y, z]: the cuboid of side
+        `cuboid_side` centred on each base point, rotated about the vertical axis by a random angle in
+        training mode (one np.random.uniform draw per frame, as the reference) and by 0 otherwise.
+        Reference: mvn/models/triangulation.py:341-385.  Built for the whole batch at once on the device
+        with the reference's float32 operation order."""
+        S = self.volume_size
+        B = base_points_np.shape[0]
+        side = float(self.cuboid_side)
+        position = base_points_np - side / 2                         # float64, host
+        step = torch.tensor(side / (S - 1), dtype=torch.float32, device=device)
+        pos = torch.from_numpy(position).to(device=device, dtype=torch.float32)         # (B,3)
+        idx = torch.arange(S, dtype=torch.float32, device=device)
+        line = pos.view(B, 3, 1) + (step * idx).view(1, 1, S)        # (B, 3, S): position + step * index
+        coord = torch.empty((B, S, S, S, 3), dtype=torch.float32, device=device)
+        coord[..., 0] = line[:, 0].view(B, S, 1, 1)
+        coord[..., 1] = line[:, 1].view(B, 1, S, 1)
+        coord[..., 2] = line[:, 2].view(B, 1, 1, S)
+        center = torch.from_numpy(base_points_np).to(device=device, dtype=torch.float32)
+        axis = [0, 1, 0] if self.kind == "coco" else [0, 0, 1]
+        thetas = [np.random.uniform(0.0, 2 * np.pi) if self.training else 0.0 for _ in range(B)]
+        rots = np.stack([volumetric.get_rotation_matrix(axis, th) for th in thetas])
+        rot = torch.from_numpy(rots).type(torch.float).to(device)     # (B,3,3)
+        c = center.view(B, 1, 1, 1, 3)
+        coord = coord - c
+        coord = torch.einsum("bij,bnj->bni", rot, coord.view(B, -1, 3)).view(B, S, S, S, 3)
+        coord = coord + c
+        if self.transfer_cmu_to_human36m:  # different world axes (triangulation.py:380-383)
+            coord = coord.permute(0, 1, 3, 2, 4).flip(2)
+        return coord.contiguous(), position
+
+    def forward(self, images, proj_matricies, batch):
+        device = images.device
+        batch_size, n_views = images.shape[:2]
+        images = images.view(-1, *images.shape[2:])
+        heatmaps, features, _, vol_confidences = self.backbone(images)
+
+        image_shape, heatmap_shape = tuple(images.shape[2:]), tuple(heatmaps.shape[2:])
+        features = features.view(batch_size, n_views, *features.shape[1:])
+        if vol_confidences is not None:
+            vol_confidences = vol_confidences.view(batch_size, n_views, *vol_confidences.shape[1:])
+        if self.volume_aggregation_method == 'conf_norm':
+            vol_confidences = vol_confidences / vol_confidences.sum(dim=1, keepdim=True)
+
+        # cameras at heatmap resolution; the projection is built in float64 on the host and cast once
+        new_cameras = deepcopy(batch['cameras'])
+        proj = np.empty((batch_size, n_views, 3, 4), dtype=np.float64)
+        for view_i in range(n_views):
+            for batch_i in range(batch_size):
+                cam = new_cameras[view_i][batch_i]
+                cam.update_after_resize(image_shape, heatmap_shape)
+                proj[batch_i, view_i] = cam.projection
+        proj_matricies = torch.from_numpy(proj).float().to(device)
+
+        base_points_np = self._base_points(batch, batch_size)
+        base_points = torch.from_numpy(base_points_np).to(device=device, dtype=torch.float32)
+        coord_volumes, positions = self.build_coord_volumes(base_points_np, device)
+        sides = np.array([self.cuboid_side, self.cuboid_side, self.cuboid_side])
+        cuboids = [volumetric.Cuboid3D(positions[i], sides) for i in range(batch_size)]
+
+        features = features.view(-1, *features.shape[2:])
+        features = self.process_features(features)
+        features = features.view(batch_size, n_views, *features.shape[1:])
+
+        with torch.no_grad():
+            volumes = op.unproject_heatmaps(features, proj_matricies, coord_volumes,
+                                            volume_aggregation_method=self.volume_aggregation_method,
+                                            vol_confidences=vol_confidences)
+        volumes = self.volume_net(volumes)
+        with torch.no_grad():
+            vol_keypoints_3d, volumes = op.integrate_tensor_3d_with_coordinates(
+                volumes, coord_volumes, softmax=self.volume_softmax, multiplier=self.volume_multiplier)
+        # same 7-tuple as the reference (triangulation.py:403)
+        return vol_keypoints_3d, features, volumes, vol_confidences, cuboids, coord_volumes, base_points

@@ -1,0 +1,156 @@
+"""Same classes and functions as the reference's mvn/utils/multiview.py.
+
+The triangulation functions run on the mvx HIP kernels (float32 device tensors in, float32 device
+tensors out, forward-only); the camera class and the small homogeneous helpers are host code, as in the
+reference, and accept numpy arrays or torch tensors.
+"""
+import numpy as np
+import torch
+
+from poseestimation_amd import _cabi
+
+_TYPE_ERROR = "Works only with numpy arrays and PyTorch tensors."
+
+
+class Camera:
+    """Pinhole camera: rotation R (3x3), translation t (3x1), intrinsics K (3x3), optional distortion.
+    Reference: mvn/utils/multiview.py:7-54."""
+
+    def __init__(self, R, t, K, dist=None, name=""):
+        self.R = np.array(R, copy=True)
+        if self.R.shape != (3, 3):
+            raise AssertionError("R must be 3x3")
+        self.t = np.array(t, copy=True)
+        if self.t.size != 3:
+            raise AssertionError("t must have 3 elements")
+        self.t = self.t.reshape(3, 1)
+        self.K = np.array(K, copy=True)
+        if self.K.shape != (3, 3):
+            raise AssertionError("K must be 3x3")
+        self.dist = None if dist is None else np.array(dist, copy=True).flatten()
+        self.name = name
+
+    def update_after_crop(self, bbox):
+        """The principal point moves with the crop's (left, upper) corner."""
+        left, upper, _right, _lower = bbox
+        self.K[0, 2] = self.K[0, 2] - left
+        self.K[1, 2] = self.K[1, 2] - upper
+
+    def update_after_resize(self, image_shape, new_image_shape):
+        """fx, cx scale with the width ratio; fy, cy with the height ratio."""
+        height, width = image_shape
+        new_height, new_width = new_image_shape
+        rx, ry = new_width / width, new_height / height
+        fx, fy, cx, cy = self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2]
+        self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2] = fx * rx, fy * ry, cx * rx, cy * ry
+
+    @property
+    def extrinsics(self):
+        return np.hstack([self.R, self.t])
+
+    @property
+    def projection(self):
+        return self.K.dot(self.extrinsics)
+
+
+def euclidean_to_homogeneous(points):
+    """(N, M) -> (N, M+1) by appending ones.  Reference: mvn/utils/multiview.py:57-71."""
+    if isinstance(points, np.ndarray):
+        return np.hstack([points, np.ones((len(points), 1))])
+    if torch.is_tensor(points):
+        ones = torch.ones((points.shape[0], 1), dtype=points.dtype, device=points.device)
+        return torch.cat([points, ones], dim=1)
+    raise TypeError(_TYPE_ERROR)
+
+
+def homogeneous_to_euclidean(points):
+    """(N, M+1) -> (N, M) by dividing by the last component.  Reference: mvn/utils/multiview.py:74-88."""
+    if isinstance(points, np.ndarray):
+        return (points.T[:-1] / points.T[-1]).T
+    if torch.is_tensor(points):
+        pt = points.transpose(1, 0)
+        return (pt[:-1] / pt[-1]).transpose(1, 0)
+    raise TypeError(_TYPE_ERROR)
+
+
+def project_3d_points_to_image_plane_without_distortion(proj_matrix, points_3d, convert_back_to_euclidean=True):
+    """(3, 4) projection of (N, 3) points -> (N, 2), or (N, 3) homogeneous when
+    convert_back_to_euclidean=False.  Reference: mvn/utils/multiview.py:91-112.
+    float32 HIP tensors go through the mvx kernel; other tensors and numpy arrays are host-side helpers."""
+    if isinstance(proj_matrix, np.ndarray) and isinstance(points_3d, np.ndarray):
+        result = euclidean_to_homogeneous(points_3d) @ proj_matrix.T
+        return homogeneous_to_euclidean(result) if convert_back_to_euclidean else result
+    if torch.is_tensor(proj_matrix) and torch.is_tensor(points_3d):
+        if (points_3d.is_cuda and proj_matrix.is_cuda and points_3d.dtype == torch.float32
+                and proj_matrix.dtype == torch.float32 and points_3d.dim() == 2 and points_3d.shape[1] == 3
+                and tuple(proj_matrix.shape) == (3, 4)):
+            P = proj_matrix.contiguous()
+            pts = points_3d.contiguous()
+            n = pts.shape[0]
+            out = torch.empty((n, 2 if convert_back_to_euclidean else 3), dtype=torch.float32, device=pts.device)
+            with torch.cuda.device(pts.device):
+                st = _cabi.load().mvx_project_points(_cabi.ptr(P), _cabi.ptr(pts), n, int(convert_back_to_euclidean),
+                                                     _cabi.ptr(out), _cabi.stream(pts.device))
+            _cabi.check(st, "mvx_project_points")
+            return out
+        result = euclidean_to_homogeneous(points_3d) @ proj_matrix.t()
+        return homogeneous_to_euclidean(result) if convert_back_to_euclidean else result
+    raise TypeError(_TYPE_ERROR)
+
+
+def triangulate_point_from_multiple_views_linear(proj_matricies, points):
+    """Host (numpy, float64) DLT of one point from N views: smallest right singular vector of the 2N x 4
+    system.  Reference: mvn/utils/multiview.py:115-140."""
+    assert len(proj_matricies) == len(points)
+    P = np.asarray(proj_matricies, dtype=np.float64)
+    pts = np.asarray(points, dtype=np.float64)
+    A = (pts[:, :, None] * P[:, 2:3, :] - P[:, :2, :]).reshape(-1, 4)
+    vh = np.linalg.svd(A, full_matrices=False)[2]
+    return homogeneous_to_euclidean(vh[3, :])
+
+
+def _dlt(proj, points, conf):
+    """proj (B,V,3,4), points (B,V,J,2), conf (B,V,J) or None -> (B,J,3) on the device of `points`."""
+    pts = _cabi.device_f32(points, "points")
+    P = _cabi.device_f32(proj, "proj_matricies").to(pts.device)
+    c = None if conf is None else _cabi.device_f32(conf, "confidences").to(pts.device)
+    b, v, j = pts.shape[:3]
+    out = torch.zeros((b, j, 3), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        st = _cabi.load().mvx_triangulate_dlt(_cabi.ptr(P), _cabi.ptr(pts), _cabi.ptr(c), b, v, j, _cabi.ptr(out),
+                                              _cabi.stream(pts.device))
+    _cabi.check(st, "mvx_triangulate_dlt")
+    return out
+
+
+def triangulate_point_from_multiple_views_linear_torch(proj_matricies, points, confidences=None):
+    """One 3-D point from (N, 3, 4) projections and (N, 2) pixel coordinates, optionally weighted by (N,)
+    confidences (default ones).  Reference: mvn/utils/multiview.py:143-172; the host LAPACK SVD there is
+    replaced by the in-register eigen-solve of the DLT kernel, with no device-to-host synchronisation."""
+    assert len(proj_matricies) == len(points)
+    n = len(points)
+    conf = None if confidences is None else confidences.reshape(1, n, 1)
+    return _dlt(proj_matricies.reshape(1, n, 3, 4), points.reshape(1, n, 1, 2), conf)[0, 0]
+
+
+def triangulate_batch_of_points(proj_matricies_batch, points_batch, confidences_batch=None):
+    """(batch, views, 3, 4), (batch, views, joints, 2), optional (batch, views, joints) ->
+    (batch, joints, 3) float32 on points_batch's device.  Reference: mvn/utils/multiview.py:175-198
+    (a Python loop over frames and joints there; one kernel launch here)."""
+    if points_batch.dim() != 4 or points_batch.shape[-1] != 2:
+        raise ValueError("points_batch must have shape (batch, views, joints, 2)")
+    b, v = points_batch.shape[:2]
+    if tuple(proj_matricies_batch.shape) != (b, v, 3, 4):
+        raise AssertionError("proj_matricies_batch must have shape %s" % ((b, v, 3, 4),))
+    if confidences_batch is not None and tuple(confidences_batch.shape) != tuple(points_batch.shape[:3]):
+        raise AssertionError("confidences_batch must have shape %s" % (tuple(points_batch.shape[:3]),))
+    return _dlt(proj_matricies_batch, points_batch, confidences_batch)
+
+
+def calc_reprojection_error_matrix(keypoints_3d, keypoints_2d_list, proj_matricies):
+    """(joints, views) matrix of half the reprojection distance.  Reference: mvn/utils/multiview.py:201-208."""
+    columns = []
+    for keypoints_2d, proj_matrix in zip(keypoints_2d_list, proj_matricies):
+        projected = project_3d_points_to_image_plane_without_distortion(proj_matrix, keypoints_3d)
+        columns.append(0.5 * np.sqrt(np.sum((keypoints_2d - projected) ** 2, axis=1)))
+    return np.vstack(columns).T

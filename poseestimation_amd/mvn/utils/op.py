@@ -1,0 +1,147 @@
+"""Same functions and signatures as the reference's mvn/utils/op.py, running on the mvx HIP kernels.
+
+All functions are forward-only (no autograd graph is recorded), take HIP device tensors and return
+freshly allocated float32 tensors on the same device, launched on torch's current stream.
+"""
+import torch
+
+from poseestimation_amd import _cabi
+
+
+def _soft_argmax_2d(heatmaps, softmax, multiplier, return_heatmaps):
+    hm = _cabi.device_f32(heatmaps, "heatmaps")
+    if hm.dim() != 4:
+        raise ValueError("heatmaps must have shape (batch, n_heatmaps, h, w), got %s" % (tuple(hm.shape),))
+    n, k, h, w = hm.shape
+    coords = torch.empty((n, k, 2), dtype=torch.float32, device=hm.device)
+    out = torch.empty_like(hm) if return_heatmaps else None
+    lib = _cabi.load()
+    with torch.cuda.device(hm.device):
+        st = lib.mvx_soft_argmax_2d(_cabi.ptr(hm), n * k, h, w, float(multiplier), int(bool(softmax)),
+                                    _cabi.ptr(coords), _cabi.ptr(out), _cabi.stream(hm.device))
+    _cabi.check(st, "mvx_soft_argmax_2d")
+    return coords, out
+
+
+def integrate_tensor_2d(heatmaps, softmax=True, *, multiplier=1.0, return_heatmaps=True):
+    """Soft-argmax of (batch, n_heatmaps, h, w) heatmaps; reference: mvn/utils/op.py:11-47.
+
+    Returns (coordinates (batch, n_heatmaps, 2) as [x, y], heatmaps): the softmax-normalised maps for
+    softmax=True, the ReLU'd maps for softmax=False (coordinates are then divided by the mass).
+    Keyword-only extras: `multiplier` folds the caller's `heatmaps * multiplier` into the kernel (each
+    element is rounded to float32 after the multiply, as the separate torch op would);
+    `return_heatmaps=False` skips the write of the normalised maps and returns None for them.
+    """
+    return _soft_argmax_2d(heatmaps, softmax, multiplier, return_heatmaps)
+
+
+def _soft_argmax_3d(volumes, coord_volumes, softmax, multiplier, return_volumes):
+    vol = _cabi.device_f32(volumes, "volumes")
+    if vol.dim() != 5:
+        raise ValueError("volumes must have shape (batch, n_volumes, x, y, z), got %s" % (tuple(vol.shape),))
+    b, n, sx, sy, sz = vol.shape
+    cv = None
+    if coord_volumes is not None:
+        cv = _cabi.device_f32(coord_volumes, "coord_volumes")
+        if tuple(cv.shape) != (b, sx, sy, sz, 3):
+            raise ValueError("coord_volumes must have shape %s, got %s" % ((b, sx, sy, sz, 3), tuple(cv.shape)))
+        if cv.device != vol.device:
+            raise ValueError("volumes and coord_volumes are on different devices")
+    coords = torch.empty((b, n, 3), dtype=torch.float32, device=vol.device)
+    out = torch.empty_like(vol) if return_volumes else None
+    lib = _cabi.load()
+    ws_bytes = lib.mvx_soft_argmax_3d_workspace_bytes(b, n, sx, sy, sz)
+    ws = torch.empty((max(ws_bytes, 8) + 7) // 8, dtype=torch.float64, device=vol.device)
+    with torch.cuda.device(vol.device):
+        st = lib.mvx_soft_argmax_3d(_cabi.ptr(vol), _cabi.ptr(cv), b, n, sx, sy, sz, float(multiplier),
+                                    int(bool(softmax)), _cabi.ptr(coords), _cabi.ptr(out), _cabi.ptr(ws),
+                                    ws.numel() * 8, _cabi.stream(vol.device))
+    _cabi.check(st, "mvx_soft_argmax_3d")
+    return coords, out
+
+
+def integrate_tensor_3d(volumes, softmax=True, *, multiplier=1.0, return_volumes=True):
+    """Soft-argmax in voxel-index space; reference: mvn/utils/op.py:50-81."""
+    return _soft_argmax_3d(volumes, None, softmax, multiplier, return_volumes)
+
+
+def integrate_tensor_3d_with_coordinates(volumes, coord_volumes, softmax=True, *, multiplier=1.0,
+                                         return_volumes=True):
+    """Expectation of the world coordinates under the (softmax of the) volumes; reference:
+    mvn/utils/op.py:84-96.  volumes (batch, n, x, y, z), coord_volumes (batch, x, y, z, 3) ->
+    (coordinates (batch, n, 3), volumes).  softmax=False is a ReLU without renormalisation, as in the
+    reference.  Keyword-only extras as in `integrate_tensor_2d`."""
+    if coord_volumes is None:
+        raise TypeError("coord_volumes is required")
+    return _soft_argmax_3d(volumes, coord_volumes, softmax, multiplier, return_volumes)
+
+
+_AGGREGATIONS = {"sum": _cabi.AGG_SUM, "max": _cabi.AGG_MAX, "softmax": _cabi.AGG_SOFTMAX}
+
+
+def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregation_method='sum', vol_confidences=None):
+    """Unprojects (batch, n_views, n_joints, h, w) maps into (batch, n_joints, x, y, z) volumes;
+    reference: mvn/utils/op.py:99-166.
+
+    proj_matricies (batch, n_views, 3, 4) project world points to map pixels; coord_volumes
+    (batch, x, y, z, 3) hold the world position of every voxel; volume_aggregation_method is 'sum', 'max',
+    'softmax' or anything starting with 'conf' (then vol_confidences (batch, n_views, n_joints) weight the
+    views).  Any other method raises ValueError, as the reference does.
+    """
+    method = volume_aggregation_method
+    if method.startswith('conf'):
+        agg = _cabi.AGG_CONF
+    elif method in _AGGREGATIONS:
+        agg = _AGGREGATIONS[method]
+    else:
+        raise ValueError("Unknown volume_aggregation_method: {}".format(method))
+    feats = _cabi.device_f32(heatmaps, "heatmaps")
+    proj = _cabi.device_f32(proj_matricies, "proj_matricies")
+    cv = _cabi.device_f32(coord_volumes, "coord_volumes")
+    if feats.dim() != 5 or cv.dim() != 5 or cv.shape[-1] != 3:
+        raise ValueError("heatmaps must be (batch, views, joints, h, w) and coord_volumes (batch, x, y, z, 3)")
+    b, v, c, h, w = feats.shape
+    if tuple(proj.shape) != (b, v, 3, 4) or cv.shape[0] != b:
+        raise ValueError("proj_matricies must be %s and coord_volumes batch %d" % ((b, v, 3, 4), b))
+    vshape = tuple(cv.shape[1:4])
+    n_vox = vshape[0] * vshape[1] * vshape[2]
+    vc = None
+    if agg == _cabi.AGG_CONF:
+        if vol_confidences is None:
+            raise ValueError("volume_aggregation_method '%s' needs vol_confidences" % method)
+        vc = _cabi.device_f32(vol_confidences, "vol_confidences")
+        if tuple(vc.shape) != (b, v, c):
+            raise ValueError("vol_confidences must have shape %s, got %s" % ((b, v, c), tuple(vc.shape)))
+    volumes = torch.empty((b, c) + vshape, dtype=torch.float32, device=feats.device)
+    lib = _cabi.load()
+    ws_bytes = lib.mvx_unproject_workspace_bytes(b, v, c, h, w)
+    ws = torch.empty((max(ws_bytes, 16) + 15) // 16 * 4, dtype=torch.float32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        st = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c, h, w, n_vox,
+                               agg, _cabi.ptr(volumes), _cabi.ptr(ws), ws.numel() * 4, _cabi.stream(feats.device))
+    _cabi.check(st, "mvx_unproject")
+    return volumes
+
+
+def gaussian_2d_pdf(coords, means, sigmas, normalize=True):
+    """Axis-aligned 2-D Gaussian density at `coords`; reference: mvn/utils/op.py:169-175 (which
+    normalises by 2*pi*sigma_x^2; kept as is)."""
+    dx = (coords[:, 0] - means[:, 0]) / sigmas[:, 0]
+    dy = (coords[:, 1] - means[:, 1]) / sigmas[:, 1]
+    value = torch.exp(-(dx * dx + dy * dy) / 2)
+    if normalize:
+        value = value / (2 * torch.pi * sigmas[:, 0] * sigmas[:, 0])
+    return value
+
+
+def render_points_as_2d_gaussians(points, sigmas, image_shape, normalize=True):
+    """One (h, w) Gaussian image per point; reference: mvn/utils/op.py:178-196."""
+    h, w = image_shape
+    ys = torch.arange(h, device=points.device, dtype=torch.float32).view(1, h, 1)
+    xs = torch.arange(w, device=points.device, dtype=torch.float32).view(1, 1, w)
+    dx = (xs - points[:, 0].view(-1, 1, 1)) / sigmas[:, 0].view(-1, 1, 1)
+    dy = (ys - points[:, 1].view(-1, 1, 1)) / sigmas[:, 1].view(-1, 1, 1)
+    images = torch.exp(-(dx * dx + dy * dy) / 2)
+    if normalize:
+        images = images / (2 * torch.pi * sigmas[:, 0] * sigmas[:, 0]).view(-1, 1, 1)
+    return images

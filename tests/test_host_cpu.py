@@ -1,0 +1,160 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol of include/mvx.h, the host-side mirror
+(camera, helpers, rotation, error types) against the reference's golden vectors, and the frame sharding
+including a world_size-2 gloo all-gather."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from poseestimation_amd import _cabi, sharding, synth
+from poseestimation_amd.mvn.utils import multiview, op, volumetric
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mvx.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(mvx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_cabi.SIGNATURES), "include/mvx.h and the ctypes table disagree"
+    lib = _cabi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mvx_version() == int(re.search(r"#define MVX_VERSION (\d+)", header).group(1))
+    assert lib.mvx_last_error() is not None
+
+
+def test_argument_validation_without_a_gpu():
+    """Shape checks run before any launch, so they can be exercised on a GPU-less host."""
+    lib = _cabi.load()
+    assert lib.mvx_soft_argmax_2d(None, 4, 96, 96, 1.0, 1, None, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert b"null" in lib.mvx_last_error()
+    assert lib.mvx_soft_argmax_2d(None, 0, 96, 96, 1.0, 1, None, None, None) == _cabi.MVX_OK      # empty batch
+    assert lib.mvx_soft_argmax_2d(None, -1, 96, 96, 1.0, 1, None, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_triangulate_dlt(None, None, None, 3, 0, 17, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_triangulate_dlt(None, None, None, 0, 4, 17, None, None) == _cabi.MVX_OK
+    assert lib.mvx_unproject(None, None, None, None, 1, 4, 32, 96, 96, 64, 9, None, None, 0, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_unproject(None, None, None, None, 1, 4, 32, 1, 96, 64, 0, None, None, 0, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_unproject_workspace_bytes(64, 4, 32, 96, 96) == 8 * 4 * 96 * 96 * 32 * 4
+    assert lib.mvx_unproject_workspace_bytes(2, 3, 5, 20, 28) == 2 * 3 * 20 * 28 * 8 * 4
+    assert lib.mvx_soft_argmax_3d_workspace_bytes(2, 17, 64, 64, 64) == 2 * 17 * 1024 * 40
+    assert lib.mvx_soft_argmax_3d(None, None, 1, 17, 0, 64, 64, 1.0, 1, None, None, None, 0, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+
+
+def test_hot_ops_refuse_cpu_tensors():
+    with pytest.raises(_cabi.MvxError):
+        op.integrate_tensor_2d(torch.zeros(1, 1, 8, 8))
+    with pytest.raises(_cabi.MvxError):
+        multiview.triangulate_batch_of_points(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 2))
+    with pytest.raises(_cabi.MvxError):
+        op.integrate_tensor_3d_with_coordinates(torch.zeros(1, 1, 2, 2, 2), torch.zeros(1, 2, 2, 2, 3))
+    with pytest.raises(ValueError, match="Unknown volume_aggregation_method"):
+        op.unproject_heatmaps(torch.zeros(1, 2, 4, 8, 8), torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 2, 2, 3), "mean")
+    with pytest.raises(TypeError):
+        op.integrate_tensor_2d(np.zeros((1, 1, 8, 8), np.float32))
+
+
+def test_camera_and_helpers_match_reference():
+    g = np.load(os.path.join(gc.GOLDEN_DIR, "helpers.npz"))
+    cam = multiview.Camera(g["R"], g["t"], g["K"])
+    K_before = g["K"].copy()
+    cam.update_after_crop((100, 50, 900, 850))
+    assert np.array_equal(cam.K, g["K_crop"]) and np.array_equal(g["K"], K_before)      # constructor copied K
+    cam.update_after_resize((800, 800), (384, 384))
+    assert np.array_equal(cam.K, g["K_resize"])
+    assert np.array_equal(cam.projection, g["P"])
+    assert cam.extrinsics.shape == (3, 4) and cam.t.shape == (3, 1)
+    assert np.array_equal(multiview.project_3d_points_to_image_plane_without_distortion(g["P"], g["pts"]), g["proj2d"])
+    assert np.array_equal(multiview.project_3d_points_to_image_plane_without_distortion(g["P"], g["pts"], False), g["proj3"])
+    Pt, pt = torch.from_numpy(g["P"]), torch.from_numpy(g["pts"])
+    np.testing.assert_allclose(multiview.project_3d_points_to_image_plane_without_distortion(Pt, pt).numpy(), g["proj2d"], rtol=1e-12)
+    h = multiview.euclidean_to_homogeneous(g["pts"])
+    assert h.shape == (9, 4) and (h[:, 3] == 1).all()
+    assert np.array_equal(multiview.homogeneous_to_euclidean(multiview.euclidean_to_homogeneous(pt)).numpy(), g["pts"])
+    for bad in ([1.0, 2.0], None):
+        with pytest.raises(TypeError, match="Works only with numpy arrays and PyTorch tensors."):
+            multiview.homogeneous_to_euclidean(bad)
+    assert np.array_equal(multiview.calc_reprojection_error_matrix(g["kp3"], list(g["kp2_list"]), list(g["Ps"])), g["reproj"])
+    P2 = np.stack([g["P"], g["P"]])
+    with pytest.raises(AssertionError):
+        multiview.triangulate_point_from_multiple_views_linear(P2, g["proj2d"][:3])
+    with pytest.raises(AssertionError):
+        multiview.Camera(np.eye(4), g["t"], g["K"])
+
+
+def test_rotation_helpers_match_reference():
+    g = np.load(os.path.join(gc.GOLDEN_DIR, "helpers.npz"))
+    assert np.array_equal(volumetric.get_rotation_matrix([0, 0, 1], 0.7), g["rot_z"])
+    assert np.array_equal(volumetric.get_rotation_matrix([1, 2, -1], 2.1), g["rot_a"])
+    assert np.array_equal(volumetric.get_rotation_matrix([0, 0, 1], 0.0), np.eye(3))
+    rotated = volumetric.rotate_coord_volume(torch.from_numpy(g["cv"]), 0.7, [0, 0, 1]).numpy()
+    np.testing.assert_allclose(rotated, g["rotated"], rtol=0, atol=1e-6)
+    box = volumetric.Cuboid3D(np.array([1.0, 2.0, 3.0]), np.array([10.0, 20.0, 30.0]))
+    lines = box.build()
+    assert len(lines) == 12
+    ends = np.array([np.concatenate([l.start_point, l.end_point]) for l in lines])
+    assert ends.min() == 1.0 and ends[:, [2, 5]].max() == 33.0
+    assert lines[0].color == (255, 0, 0) and lines[3].color == (255, 255, 0)
+
+
+def test_synthetic_inputs_are_reproducible():
+    a = synth.algebraic_case(11, 2, 4)
+    b = synth.algebraic_case(11, 2, 4)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["heatmaps"].shape == (2, 4, 17, 96, 96) and a["heatmaps"].dtype == np.float32
+    # blobs sit at the projected joints: the arg-max is within a pixel or two of proj/4 where it is inside the map
+    centres = synth.project(a["proj"], a["joints_3d"]) / 4
+    inside = ((centres > 3) & (centres < 92)).all(-1)
+    flat = a["heatmaps"].reshape(2, 4, 17, -1).argmax(-1)
+    peak = np.stack([flat % 96, flat // 96], -1)
+    assert np.abs(peak - centres)[inside].max() < 3.0
+    v = synth.volumetric_case(12, 1, 4, volume_size=8)
+    assert v["coord_volumes"].shape == (1, 8, 8, 8, 3) and v["volumes"].shape == (1, 17, 8, 8, 8)
+    step = np.float32(2500.0 / 7)
+    assert np.allclose(np.diff(v["coord_volumes"][0, :, 0, 0, 0]), step)
+
+
+def test_shard_bounds_cover_all_frames():
+    for n, w in ((65536, 8), (10, 4), (3, 8), (0, 2), (17, 1)):
+        spans = [sharding.shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sharding.shard_sizes(n, w)
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(4, 2, 2)
+    single = torch.arange(12.0).view(2, 2, 3)
+    assert sharding.all_gather_keypoints(single, 2) is single      # not distributed: identity
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from poseestimation_amd import sharding
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+for total in (7, 8, 1):
+    a, b = sharding.shard_bounds(total, rank, world)
+    local = torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1).expand(-1, 17, 3).contiguous() * 1.5
+    full = sharding.all_gather_keypoints(local, total)
+    want = torch.arange(total, dtype=torch.float32).view(-1, 1, 1).expand(-1, 17, 3) * 1.5
+    assert full.shape == (total, 17, 3) and torch.equal(full, want), (rank, total)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_all_gather_keypoints_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]

@@ -1,0 +1,126 @@
+"""The drop-in model classes (stub backbone / volume net) against the reference's own forward outputs stored
+in tests/golden/model_forward.npz, and the multi-view glue around them."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import mvn_oracle as orc
+from poseestimation_amd import synth
+from poseestimation_amd.mvn.models.triangulation import AlgebraicTriangulationNet, VolumetricTriangulationNet
+from poseestimation_amd.mvn.utils import multiview
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class StubBackbone(torch.nn.Module):
+    def __init__(self, heatmaps, features, alg_conf, vol_conf):
+        super().__init__()
+        self.out = (heatmaps, features, alg_conf, vol_conf)
+
+    def forward(self, images):
+        return self.out
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+
+
+def ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def test_algebraic_forward_matches_reference_forward():
+    g = np.load(os.path.join(gc.GOLDEN_DIR, "model_forward.npz"))
+    case = gc.algebraic_inputs("alg_b2v4")
+    hm, conf, proj = case["heatmaps"], case["confidences"], case["proj"]
+    assert gc.sha(hm, conf, proj) == str(g["alg_input_sha"])
+    B, V, J, h, w = hm.shape
+    cfg = ns(model=ns(use_confidences=True, heatmap_softmax=True, heatmap_multiplier=100.0,
+                      backbone=ns(alg_confidences=None, vol_confidences=None)))
+    net = AlgebraicTriangulationNet(cfg, device=DEV, backbone=StubBackbone(t(hm).view(B * V, J, h, w), None, t(conf).view(B * V, J), None))
+    assert cfg.model.backbone.alg_confidences is True and cfg.model.backbone.vol_confidences is False
+    out = net(torch.zeros(B, V, 3, 384, 384, device=DEV), t(proj), None)
+    assert len(out) == 6
+    kp3d, kp2d, hm_out, c, t1, t2 = out
+    assert isinstance(t1, float) and isinstance(t2, float) and t2 >= t1
+    assert kp3d.shape == (B, J, 3) and kp2d.shape == (B, V, J, 2) and hm_out.shape == (B, V, J, h, w) and c.shape == (B, V, J)
+    # against the reference's float32 forward: 2-D within its float32 soft-argmax noise (x4 upscale),
+    # 3-D within what that 2-D noise moves the point
+    assert np.abs(kp2d.cpu().numpy() - g["alg_kp2d"]).max() < 4 * 2e-4
+    assert np.abs(kp3d.cpu().numpy() - g["alg_kp3d"]).max() < 5e-2
+    np.testing.assert_allclose(c.cpu().numpy(), g["alg_conf"], rtol=2.5e-7)
+    np.testing.assert_allclose(hm_out[0, :, :, ::7, ::5].cpu().numpy(), g["alg_hm_sample"], rtol=2e-4, atol=1e-12)
+    # against the float64 oracle: the stated tolerances
+    o3d, o2d, ohm, oconf = orc.algebraic_forward(hm, conf, proj)
+    assert np.abs(kp2d.cpu().numpy() - o2d).max() <= 4 * 1e-5
+    assert np.abs(kp3d.cpu().numpy() - o3d).max() <= 1e-3
+    assert np.array_equal(c.cpu().numpy(), oconf)
+
+
+def test_algebraic_without_confidences_uses_ones():
+    case = synth.algebraic_case(77, 1, 4)
+    hm, proj = case["heatmaps"], case["proj"]
+    cfg = ns(model=ns(use_confidences=False, heatmap_softmax=True, heatmap_multiplier=100.0,
+                      backbone=ns(alg_confidences=None, vol_confidences=None)))
+    net = AlgebraicTriangulationNet(cfg, device=DEV, backbone=StubBackbone(t(hm).view(4, 17, 96, 96), None, None, None))
+    kp3d, kp2d, _, c, _, _ = net(torch.zeros(1, 4, 3, 384, 384, device=DEV), t(proj), None)
+    assert torch.allclose(c, torch.full_like(c, 0.25 + 1e-5))
+    o3d, _, _, _ = orc.algebraic_forward(hm, np.ones((1, 4, 17), np.float32), proj)
+    assert np.abs(kp3d.cpu().numpy() - o3d).max() <= 1e-3
+
+
+@pytest.mark.parametrize("kind,method,training", [("mpii", "softmax", False), ("coco", "conf_norm", False), ("mpii", "sum", True)])
+def test_volumetric_forward_matches_reference_forward(kind, method, training):
+    g = np.load(os.path.join(gc.GOLDEN_DIR, "model_forward.npz"))
+    rng = np.random.default_rng(1500)
+    B, V, S, hs, img = 2, 3, 8, 24, 96
+    K, R, tv = synth.make_cameras(rng, B, V, image_size=img)
+    feats256 = rng.standard_normal((B * V, 256, hs, hs)).astype(np.float32)
+    heat = rng.standard_normal((B * V, 17, hs, hs)).astype(np.float32)
+    vconf = rng.uniform(0.1, 1.0, (B * V, 32)).astype(np.float32)
+    w_pf = (rng.standard_normal((32, 256, 1, 1)) * 0.05).astype(np.float32)
+    b_pf = (rng.standard_normal(32) * 0.1).astype(np.float32)
+    w_vn = (rng.standard_normal((17, 32, 1, 1, 1)) * 0.5).astype(np.float32)
+    kp3 = synth.make_joints_3d(rng, B)
+    assert gc.sha(feats256, heat, vconf, w_pf, b_pf, w_vn) == str(g["vol_feats_sha"])
+    cfg = ns(model=ns(volume_aggregation_method=method, volume_softmax=True, volume_multiplier=1.0, volume_size=S,
+                      cuboid_side=2500.0, kind=kind, use_gt_pelvis=True, heatmap_softmax=True, heatmap_multiplier=100.0,
+                      backbone=ns(num_joints=17, alg_confidences=None, vol_confidences=None)))
+    vol_net = torch.nn.Conv3d(32, 17, 1, bias=False)
+    vol_net.weight.data = torch.from_numpy(w_vn)
+    net = VolumetricTriangulationNet(
+        cfg, device=DEV, volume_net=vol_net,
+        backbone=StubBackbone(t(heat), t(feats256), None, t(vconf) if method.startswith("conf") else None))
+    assert cfg.model.backbone.vol_confidences is method.startswith("conf")
+    net.process_features[0].weight.data = torch.from_numpy(w_pf)
+    net.process_features[0].bias.data = torch.from_numpy(b_pf)
+    net = net.to(DEV)
+    net.train(training)
+    assert sorted(k.split(".")[0] for k in net.state_dict()) == ["process_features"] * 2 + ["volume_net"]
+    cams = [[multiview.Camera(R[v], tv[v], K[b, v]) for b in range(B)] for v in range(V)]
+    batch = {"cameras": cams, "keypoints_3d": [kp3[b] for b in range(B)]}
+    np.random.seed(7)
+    with torch.no_grad():
+        out = net(torch.zeros(B, V, 3, img, img, device=DEV), None, batch)
+    assert len(out) == 7
+    kp, f, vols, vc, cuboids, cvol, base = out
+    tag = "vol_%s_%s_%s" % (kind, method, "train" if training else "eval")
+    # the caller's cameras are left untouched (the reference deep-copies them)
+    assert np.array_equal(cams[0][0].K, K[0, 0])
+    assert np.array_equal(base.cpu().numpy(), g[tag + "_base_points"])
+    np.testing.assert_allclose(np.stack([c.position for c in cuboids]), g[tag + "_cuboid_pos"], rtol=0, atol=0)
+    if training:   # rotated volumes: float32 3x3 products may round differently on the device
+        np.testing.assert_allclose(cvol.cpu().numpy(), g[tag + "_coord_volumes"], rtol=0, atol=2e-3)
+    else:
+        assert np.array_equal(cvol.cpu().numpy(), g[tag + "_coord_volumes"])
+    np.testing.assert_allclose(f.cpu().numpy(), g[tag + "_features"], rtol=1e-4, atol=1e-5)
+    if vc is not None:
+        np.testing.assert_allclose(vc.cpu().numpy(), g[tag + "_vol_conf"], rtol=1e-6)
+    # volumes come out of a softmax over 512 voxels; keypoints are millimetres
+    np.testing.assert_allclose(vols.cpu().numpy(), g[tag + "_volumes"], rtol=5e-3, atol=1e-7)
+    assert np.abs(kp.cpu().numpy() - g[tag + "_kp3d"]).max() < (0.5 if training else 5e-2)
