@@ -34,24 +34,26 @@ struct Tap {
     unsigned pixel;            // yb * W + xb, always inside the map
 };
 
-// Projects one voxel with P (3x4, row-major), converts to the sampling position exactly as the reference's
-// float32 sequence does -- x/z, then gx = 2(x/H - 0.5), gy = 2(y/W - 0.5) (H for x and W for y), then
-// grid_sample(align_corners=True): ix = (gx + 1)/2 * (W - 1), iy = (gy + 1)/2 * (H - 1) -- and returns
-// the bilinear taps with zero padding.  A voxel with z <= 0 gets all-zero weights.
+// Projects one voxel with P (3x4, row-major) and returns the bilinear taps with zero padding.
+// The reference maps the projected pixel (x, y) = (u/z, v/z) through gx = 2(x/H - 0.5), gy = 2(y/W - 0.5)
+// (H for x and W for y) and grid_sample(align_corners=True): ix = (gx + 1)/2 * (W - 1) = x/H * (W - 1),
+// iy = y/W * (H - 1).  The position is evaluated in float64 and only the interpolation weights are rounded
+// to float32: the reference's float32 position carries about 1e-5 px of rounding noise, which would
+// otherwise be multiplied by the feature gradient.  A voxel with z <= 0 gets all-zero weights.
 __device__ __forceinline__ Tap project_tap(const float* __restrict__ P, float cx, float cy, float cz, int H, int W) {
-    const float u = fmaf(cx, P[0], fmaf(cy, P[1], fmaf(cz, P[2], P[3])));
-    const float v = fmaf(cx, P[4], fmaf(cy, P[5], fmaf(cz, P[6], P[7])));
-    const float z = fmaf(cx, P[8], fmaf(cy, P[9], fmaf(cz, P[10], P[11])));
-    const bool behind = z <= 0.0f;
-    const float zz = (z == 0.0f) ? 1.0f : z;
-    const float x = u / zz, y = v / zz;
-    const float gx = 2.0f * (x / static_cast<float>(H) - 0.5f);
-    const float gy = 2.0f * (y / static_cast<float>(W) - 0.5f);
-    const float ix = ((gx + 1.0f) / 2.0f) * static_cast<float>(W - 1);
-    const float iy = ((gy + 1.0f) / 2.0f) * static_cast<float>(H - 1);
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const float wx0 = (x0f + 1.0f) - ix, wx1 = ix - x0f;
-    const float wy0 = (y0f + 1.0f) - iy, wy1 = iy - y0f;
+    const double X = cx, Y = cy, Z = cz;
+    const double u = fma(X, static_cast<double>(P[0]), fma(Y, static_cast<double>(P[1]), fma(Z, static_cast<double>(P[2]), static_cast<double>(P[3]))));
+    const double v = fma(X, static_cast<double>(P[4]), fma(Y, static_cast<double>(P[5]), fma(Z, static_cast<double>(P[6]), static_cast<double>(P[7]))));
+    const double z = fma(X, static_cast<double>(P[8]), fma(Y, static_cast<double>(P[9]), fma(Z, static_cast<double>(P[10]), static_cast<double>(P[11]))));
+    const bool behind = z <= 0.0;
+    const double rz = 1.0 / ((z == 0.0) ? 1.0 : z);
+    const double ixd = (u * rz) / static_cast<double>(H) * static_cast<double>(W - 1);
+    const double iyd = (v * rz) / static_cast<double>(W) * static_cast<double>(H - 1);
+    const double x0d = floor(ixd), y0d = floor(iyd);
+    const float wx1 = static_cast<float>(ixd - x0d), wy1 = static_cast<float>(iyd - y0d);
+    const float wx0 = static_cast<float>((x0d + 1.0) - ixd), wy0 = static_cast<float>((y0d + 1.0) - iyd);
+    const float ix = static_cast<float>(ixd), iy = static_cast<float>(iyd);
+    const float x0f = static_cast<float>(x0d), y0f = static_cast<float>(y0d);
     // clamp before the conversion so that far-away or non-finite positions become "outside"
     const int x0 = static_cast<int>(fminf(fmaxf(x0f, -2.0f), static_cast<float>(W)));
     const int y0 = static_cast<int>(fminf(fmaxf(y0f, -2.0f), static_cast<float>(H)));

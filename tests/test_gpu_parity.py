@@ -1,6 +1,8 @@
 """HIP kernels (through the C ABI and the mvn mirror) against the float64 oracle and the reference's golden
 vectors.  Tolerances: soft-argmax coordinates 1e-5 px, triangulated joints 1e-3 mm, volumetric keypoints
-1e-3 mm (absolute; a relative float32 term is added only where values leave the capture volume)."""
+1e-3 mm (absolute; a relative float32 term is added only where values leave the capture volume).
+Normalised heatmaps / volumes: 2e-5 relative -- exp(d) in float32 carries a relative error of about
+|d| * 1e-7, which reaches 1e-5 only for probabilities below e^-80."""
 import os
 
 import numpy as np
@@ -16,6 +18,8 @@ pytestmark = pytest.mark.gpu
 
 PX_TOL = 1e-5
 MM_TOL = 1e-3
+UNPROJ_TOL = 5e-6        # unprojected features (N(0,1) maps) against the float64 oracle
+UNPROJ_REF32_TOL = 1e-4  # against the float32 reference, which differs from its own float64 evaluation by 4.4e-5
 
 
 def dev():
@@ -55,7 +59,7 @@ def test_soft_argmax_2d_golden_cases(name):
     assert np.abs(c - g["coords_ref64"]).max() <= PX_TOL
     # against the float32 reference: inside the reference's own float32 noise
     assert np.abs(c - g["coords_ref32"]).max() < 2e-4
-    np.testing.assert_allclose(out.cpu().numpy(), o_out, rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(out.cpu().numpy(), o_out, rtol=2e-5, atol=1e-30)
     # the same call without the multiplier fold: multiply first in torch, as the reference's caller does
     coords2, _ = op.integrate_tensor_2d(to_dev(hm).view(B * V, J, h, w) * 100.0, sm)
     assert torch.equal(coords, coords2)
@@ -71,8 +75,9 @@ def test_soft_argmax_2d_shapes(shape, softmax):
     hm = (rng.standard_normal(shape) * 3).astype(np.float32)
     coords, out = op.integrate_tensor_2d(to_dev(hm), softmax, multiplier=1.0)
     o_coords, o_out = orc.integrate_tensor_2d(hm, softmax)
-    assert np.abs(coords.cpu().numpy() - o_coords).max() <= PX_TOL
-    np.testing.assert_allclose(out.cpu().numpy(), o_out, rtol=2e-6, atol=1e-30)
+    # softmax=False on a map without a positive value is 0/0 = NaN on both sides
+    np.testing.assert_allclose(coords.cpu().numpy(), o_coords, rtol=0, atol=PX_TOL, equal_nan=True)
+    np.testing.assert_allclose(out.cpu().numpy(), o_out, rtol=2e-5, atol=1e-30)
 
 
 def test_soft_argmax_2d_edge_cases():
@@ -178,10 +183,10 @@ def test_unproject_small_generic_kernel(method):
     out = op.unproject_heatmaps(to_dev(feats), to_dev(proj), to_dev(coord), method, to_dev(vconf)).cpu().numpy()
     ref = orc.unproject_heatmaps(feats, proj, coord, method, vconf)
     assert out.shape == ref.shape
-    # sampling positions are computed in float32 as the reference computes them; against float64 the
-    # difference is the position rounding (about 1e-5 px) times the feature gradient
-    assert np.abs(out - ref).max() < 1e-4
-    assert np.abs(out - g["unproj_%s_ref32" % method]).max() < 1e-4
+    # sampling positions are exact (float64); taps and aggregation are float32
+    assert np.abs(out - ref).max() < UNPROJ_TOL
+    # the float32 reference's own position rounding (about 1e-5 px, times the feature gradient)
+    assert np.abs(out - g["unproj_%s_ref32" % method]).max() < UNPROJ_REF32_TOL
     # voxels the reference zeroes (behind every camera or outside every map) are exactly zero here too
     if method == "sum":
         assert np.array_equal(out == 0, g["unproj_sum_ref32"] == 0)
@@ -195,11 +200,13 @@ def test_unproject_full_size_tile_kernel(method):
     out = op.unproject_heatmaps(to_dev(feats), to_dev(proj), to_dev(coord), method, to_dev(vconf)).cpu().numpy()
     assert out.shape == (1, 32, 64, 64, 64)
     sample = out.reshape(32, -1)[:, ::gc.FULL_VOL_STRIDE]
-    assert np.abs(sample - g["unproj_%s_ref32" % method]).max() < 1e-4
+    assert np.abs(sample - g["unproj_%s_ref32" % method]).max() < UNPROJ_REF32_TOL
+    if method in ("softmax", "conf"):
+        assert np.abs(sample - g["unproj_%s_ref64" % method]).max() < UNPROJ_TOL
     # a dense slab against the oracle (every channel, 4096 consecutive voxels spanning 32 tiles)
     sub = np.arange(100000, 104096)
     ref = orc.unproject_heatmaps(feats, proj, coord, method, vconf, voxel_subset=sub)[0]
-    assert np.abs(out.reshape(32, -1)[:, sub] - ref).max() < 1e-4
+    assert np.abs(out.reshape(32, -1)[:, sub] - ref).max() < UNPROJ_TOL
 
 
 def test_unproject_tile_and_generic_kernels_agree():
@@ -249,13 +256,13 @@ def test_soft_argmax_3d_small(softmax):
     c, v = op.integrate_tensor_3d_with_coordinates(to_dev(vols), to_dev(coord), softmax)
     oc, ov = orc.integrate_tensor_3d_with_coordinates(vols, coord, softmax)
     assert (np.abs(c.cpu().numpy() - oc) <= MM_TOL + 1e-6 * np.abs(oc)).all()
-    np.testing.assert_allclose(v.cpu().numpy(), ov, rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(v.cpu().numpy(), ov, rtol=2e-5, atol=1e-30)
     r32 = g["int3dc_%s_coords_ref32" % tag]
     assert (np.abs(c.cpu().numpy() - r32) <= 5e-2 + 2e-6 * np.abs(r32)).all()
     ci, vi = op.integrate_tensor_3d(to_dev(vols), softmax)
     oci, ovi = orc.integrate_tensor_3d(vols, softmax)
     assert np.abs(ci.cpu().numpy() - oci).max() < 1e-5
-    np.testing.assert_allclose(vi.cpu().numpy(), ovi, rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(vi.cpu().numpy(), ovi, rtol=2e-5, atol=1e-30)
 
 
 @pytest.mark.parametrize("multiplier", [1.0, 3.5])
@@ -266,7 +273,7 @@ def test_soft_argmax_3d_full_size(multiplier):
     c, v = op.integrate_tensor_3d_with_coordinates(to_dev(vols), to_dev(coord), True, multiplier=multiplier)
     oc, ov = orc.integrate_tensor_3d_with_coordinates(vols * np.float32(multiplier), coord, True)
     assert np.abs(c.cpu().numpy() - oc).max() <= MM_TOL
-    np.testing.assert_allclose(v.cpu().numpy(), ov, rtol=3e-6, atol=1e-30)
+    np.testing.assert_allclose(v.cpu().numpy(), ov, rtol=2e-5, atol=1e-30)
     if multiplier == 1.0:
         assert np.abs(c.cpu().numpy() - g["int3dc_coords_ref64"]).max() <= MM_TOL
         assert np.abs(c.cpu().numpy() - g["int3dc_coords_ref32"]).max() < 5e-3   # the reference's own float32 noise
