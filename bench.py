@@ -1,0 +1,276 @@
+"""Throughput of the multi-view triangulation path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload algebraic|volumetric|stream16]
+
+A step is one pass of the path over one resident batch of synthetic frames:
+  algebraic  (default; BASELINE.json configs[1]) 4096 frames x 4 views x 17 joints of 96x96 heatmaps per GPU:
+             soft-argmax (multiplier folded in, normalised heatmaps written back as the reference returns them)
+             -> confidence normalisation + keypoint upscale + DLT.
+  volumetric (configs[2]) 64 frames: 4 views x 32-channel 96x96 features unprojected into 64^3 (softmax
+             aggregation), 17 volumes per frame soft-argmaxed with coordinates (normalised volumes written).
+  stream16   (configs[4]) 16 views: p50 latency of one frame and throughput at 1024 frames.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds its own batch (weak scaling,
+frames sharded across ranks) and each step ends with the RCCL all-gather of the (frames, 17, 3) keypoints.
+Rank 0 prints one JSON line; `value` is the whole-job frames/s with inputs resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from poseestimation_amd import _cabi, sharding, synth  # noqa: E402
+from poseestimation_amd.mvn.models.triangulation import AlgebraicTriangulationNet  # noqa: E402
+from poseestimation_amd.mvn.utils import op  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+
+
+def algebraic_head():
+    net = AlgebraicTriangulationNet.__new__(AlgebraicTriangulationNet)
+    torch.nn.Module.__init__(net)
+    net.use_confidences, net.heatmap_softmax, net.heatmap_multiplier = True, True, 100.0
+    return net
+
+
+class EventTimer:
+    """HIP events on torch's current stream (the stream the kernels are launched on), one pair per launch."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.pairs.append((self.a, self.b))
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
+
+
+def cpu_baseline_algebraic(n_views, sample_frames):
+    """The torch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload, host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_port
+    threads = torch.get_num_threads()
+    case = synth.algebraic_case(1234 + 1, sample_frames, n_views)
+    secs = torch_port.time_algebraic(case, repeats=9, warmup=2)
+    return {"value": sample_frames / secs, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames x %d views x 17 joints, soft-argmax + glue + per-point host SVD, median of 9 passes" %
+                      (sample_frames, n_views)}
+
+
+def cpu_baseline_volumetric(sample_frames):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_port
+    threads = torch.get_num_threads()
+    case = synth.volumetric_case(1234 + 2, sample_frames, 4)
+    f, p, c, vc, vol = (torch.from_numpy(case[k]) for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
+    ts = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            torch_port.unproject(f, p, c, "softmax", vc)
+            torch_port.soft_argmax_3d_coords(vol, c)
+            if i >= 1:
+                ts.append(time.perf_counter() - t0)
+    secs = float(np.median(ts))
+    return {"value": sample_frames / secs, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames, unproject (softmax) + 3-D soft-argmax, median of 2" % sample_frames}
+
+
+def run_algebraic(args, dev, rank, world, n_views=4, frames=4096, writeback=True):
+    case = synth.device_algebraic_case(1234 + 1 + rank, frames, n_views, dev)
+    hm, conf, proj = case["heatmaps"], case["confidences"], case["proj"]
+    net = algebraic_head()
+    b, v, j, h, w = hm.shape
+    lib = _cabi.load()
+    k1 = EventTimer()
+    k2 = EventTimer()
+    kp_hm = torch.empty((b * v, j, 2), dtype=torch.float32, device=dev)
+    hm_out = torch.empty_like(hm) if writeback else None
+    kp_img = torch.empty((b, v, j, 2), dtype=torch.float32, device=dev)
+    conf_n = torch.empty((b, v, j), dtype=torch.float32, device=dev)
+    kp3d = torch.empty((b, j, 3), dtype=torch.float32, device=dev)
+    st = _cabi.stream(dev)
+
+    def step(timed):
+        # the two C-ABI calls AlgebraicTriangulationNet.triangulate_from_heatmaps makes, with outputs preallocated
+        if timed:
+            with k1:
+                rc = lib.mvx_soft_argmax_2d(_cabi.ptr(hm), b * v * j, h, w, 100.0, 1, _cabi.ptr(kp_hm), _cabi.ptr(hm_out), st)
+            with k2:
+                rc |= lib.mvx_algebraic_glue_dlt(_cabi.ptr(proj), _cabi.ptr(kp_hm), _cabi.ptr(conf), b, v, j, 384.0 / w,
+                                                 384.0 / h, _cabi.ptr(kp_img), _cabi.ptr(conf_n), _cabi.ptr(kp3d), st)
+        else:
+            rc = lib.mvx_soft_argmax_2d(_cabi.ptr(hm), b * v * j, h, w, 100.0, 1, _cabi.ptr(kp_hm), _cabi.ptr(hm_out), st)
+            rc |= lib.mvx_algebraic_glue_dlt(_cabi.ptr(proj), _cabi.ptr(kp_hm), _cabi.ptr(conf), b, v, j, 384.0 / w,
+                                             384.0 / h, _cabi.ptr(kp_img), _cabi.ptr(conf_n), _cabi.ptr(kp3d), st)
+        if rc != 0:
+            raise RuntimeError("mvx call failed: %s" % lib.mvx_last_error().decode())
+        if world > 1:
+            return sharding.all_gather_keypoints(kp3d, frames * world)
+        return kp3d
+
+    # the drop-in class path gives the same numbers as the preallocated calls
+    ref3d = net.triangulate_from_heatmaps(hm[:8], conf[:8], proj[:8], (384, 384))[0]
+    out = step(False)
+    own = out[rank * frames: rank * frames + 8] if world > 1 else out[:8]
+    assert torch.equal(own, ref3d)
+    # sanity: synthetic joints are recovered to within the blob noise
+    err = (own.cpu().numpy() - case["joints_3d"][:8]).__abs__().max()
+    assert err < 80.0, "triangulated joints are %g mm from the synthetic ground truth" % err
+
+    ms = timed_loop(step, args, dev, world)
+    bytes_per_launch = frames * v * j * h * w * 4 * (2 if writeback else 1) + frames * v * j * 8
+    roof = {"bound": "hbm", "kernel": "soft_argmax_2d_reg<9>", "achieved": bytes_per_launch / (k1.mean_ms() * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1.mean_ms()}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    extra = {"dlt_kernel_ms": k2.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err)}
+    cfg = {"workload": "algebraic: soft-argmax 2D + confidence-weighted DLT, %d frames/GPU x %d views x 17 joints, 96x96 heatmaps"
+                       % (frames, v), "frames_per_gpu": frames, "views": v, "joints": j, "heatmap_writeback": writeback,
+           "parallelism": "frames sharded over %d GPU(s), all-gather of keypoints" % world}
+    return ms, frames, roof, cfg, extra
+
+
+def run_volumetric(args, dev, rank, world, frames=64):
+    case = synth.device_volumetric_case(1234 + 2 + rank, frames, 4, dev)
+    feats, proj, coord, vconf, vols = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
+    k3 = EventTimer()
+    k4 = EventTimer()
+
+    def step(timed):
+        if timed:
+            with k3:
+                u = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
+            with k4:
+                kp, _ = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
+        else:
+            u = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
+            kp, _ = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
+        del u
+        if world > 1:
+            return sharding.all_gather_keypoints(kp, frames * world)
+        return kp
+
+    step(False)
+    ms = timed_loop(step, args, dev, world)
+    n_vox = 64 ** 3
+    b3 = frames * (4 * 32 * 96 * 96 * 4 + n_vox * 12 + 32 * n_vox * 4)
+    b4 = frames * (17 * n_vox * 4 * 2 + n_vox * 12)
+    roof = {"bound": "hbm", "kernel": "unproject (channel-last copy + unproject_tile32<softmax>)",
+            "achieved": b3 / (k3.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "algorithmic_bytes_per_launch": b3, "avg_launch_ms": k3.mean_ms()}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    extra = {"soft_argmax_3d_ms": k4.mean_ms(), "soft_argmax_3d_GBps": b4 / (k4.mean_ms() * 1e-3) / 1e9}
+    cfg = {"workload": "volumetric: unproject 4 views x 32ch 96x96 -> 64^3 (softmax) + 3-D soft-argmax of 17 volumes, %d frames/GPU"
+                       % frames, "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world}
+    return ms, frames, roof, cfg, extra
+
+
+def timed_loop(step, args, dev, world):
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    secs = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([secs], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        secs = float(t.item())
+    return secs * 1e3 / args.steps
+
+
+def latency_p50(dev, n_views=16, launches=1000):
+    """One frame, 16 views: host-visible p50 of soft-argmax + DLT, each launch synchronised."""
+    case = synth.device_algebraic_case(1234 + 5, 1, n_views, dev)
+    net = algebraic_head()
+    hm, conf, proj = case["heatmaps"], case["confidences"], case["proj"]
+    for _ in range(50):
+        net.triangulate_from_heatmaps(hm, conf, proj, (384, 384))
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(launches):
+        t0 = time.perf_counter()
+        net.triangulate_from_heatmaps(hm, conf, proj, (384, 384))
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    return float(np.percentile(ts, 50) * 1e6), float(np.percentile(ts, 99) * 1e6)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="algebraic", choices=["algebraic", "volumetric", "stream16"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
+    ap.add_argument("--no-writeback", action="store_true", help="algebraic: skip the normalised-heatmap output")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://")
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    _cabi.load()  # fails loudly if libmvx.so was not built
+
+    extra = {}
+    if args.workload == "algebraic":
+        ms, frames, roof, cfg, extra = run_algebraic(args, dev, rank, world, 4, args.frames or 4096, not args.no_writeback)
+        metric = "triangulated frames/sec (4-view, 17-joint)"
+    elif args.workload == "volumetric":
+        ms, frames, roof, cfg, extra = run_volumetric(args, dev, rank, world, args.frames or 64)
+        metric = "volumetric frames/sec (4-view unproject to 64^3 + 3-D soft-argmax, 17 joints)"
+    else:
+        ms, frames, roof, cfg, extra = run_algebraic(args, dev, rank, world, 16, args.frames or 1024, not args.no_writeback)
+        metric = "triangulated frames/sec (16-view, 17-joint)"
+        if rank == 0:
+            p50, p99 = latency_p50(dev)
+            extra["batch1_16view_latency_p50_us"] = p50
+            extra["batch1_16view_latency_p99_us"] = p99
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        if args.workload == "volumetric":
+            cpu = cpu_baseline_volumetric(4)
+        else:
+            cpu = cpu_baseline_algebraic(16 if args.workload == "stream16" else 4, 64 if args.workload == "stream16" else 256)
+
+    if rank == 0:
+        line = {"metric": metric, "value": frames * world / (ms * 1e-3), "unit": "frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
+                "roofline": roof, "cpu_baseline": cpu, "extra": extra}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
