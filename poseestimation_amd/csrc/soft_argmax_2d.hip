@@ -8,6 +8,8 @@
 //
 // Arithmetic: t = float32(x * multiplier); m = max t (exact); e = exp(t - m) in float32;
 // S = sum e, Sx = sum e*col, Sy = sum e*row in float64; x = Sx/S, y = Sy/S rounded once to float32.
+#include <stdlib.h>
+
 #include "mvx_common.h"
 
 namespace mvx {
@@ -56,6 +58,24 @@ __device__ __forceinline__ void accumulate4(const float4& e, int row, int col, d
     sx += fma(3.0, e3, fma(2.0, e2, e1));
 }
 
+typedef float vec4f __attribute__((ext_vector_type(4)));
+// Streaming (non-temporal) 16-byte accesses: every byte is touched once, so nothing is worth keeping in cache.
+__device__ __forceinline__ float4 load_f4(const float4* p, bool nt) {
+    if (nt) {
+        const vec4f r = __builtin_nontemporal_load(reinterpret_cast<const vec4f*>(p));
+        return make_float4(r.x, r.y, r.z, r.w);
+    }
+    return *p;
+}
+__device__ __forceinline__ void store_f4(float4* p, const float4& v, bool nt) {
+    if (nt) {
+        vec4f r = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(r, reinterpret_cast<vec4f*>(p));
+    } else {
+        *p = v;
+    }
+}
+
 // h*w == 256*4*NV and w % 4 == 0: the map lives in NV float4 registers per thread.
 template <int NV>
 __global__ __launch_bounds__(kThreads) void soft_argmax_2d_reg(const float* __restrict__ hm, int w, float mult,
@@ -69,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_2d_reg(const float* __re
 
     float4 v[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = src[k * kThreads + tid];
+    for (int k = 0; k < NV; ++k) v[k] = load_f4(src + k * kThreads + tid, true);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         v[k].x *= mult;
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_2d_reg(const float* __re
             p.y *= inv;
             p.z *= inv;
             p.w *= inv;
-            dst[k * kThreads + tid] = p;
+            store_f4(dst + k * kThreads + tid, p, true);
         }
     }
 }
@@ -210,14 +230,29 @@ extern "C" int mvx_soft_argmax_2d(const float* heatmaps, int64_t n_maps, int h, 
     const dim3 grid(static_cast<unsigned>(n_maps)), block(kThreads);
     const int hw = h * w;
     const bool vec_ok = (w % 4 == 0) && aligned16(heatmaps) && (heatmaps_out == nullptr || aligned16(heatmaps_out));
+    // Every map is read once and written once.  With the write-back, HBM sustains more when few maps are in
+    // flight per CU (about 72 KB, i.e. 2 resident workgroups for 96x96 maps, measured best on MI355X: the reads
+    // and writes of the whole chip then stay inside a window of a few MB); LDS the kernel does not use is
+    // requested only to cap the residency.  Without the write-back the stream is read-only and twice that
+    // (4 workgroups) is best.
+    const char* be = getenv("MVX_SAM2D_BLOCKS_PER_CU");
+    int per_cu = 8;
+    if (be != nullptr) {
+        per_cu = atoi(be);
+    } else {
+        const int64_t in_flight = (heatmaps_out != nullptr ? 72 : 144) * 1024;
+        per_cu = static_cast<int>((in_flight + static_cast<int64_t>(hw) * 2) / (static_cast<int64_t>(hw) * 4));
+    }
+    if (per_cu < 1) per_cu = 1;
+    const size_t cap_lds = per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
     if (vec_ok && hw == kThreads * 4 * 9) {  // 96 x 96
-        hipLaunchKernelGGL(soft_argmax_2d_reg<9>, grid, block, 0, st, heatmaps, w, multiplier, softmax, coords,
+        hipLaunchKernelGGL(soft_argmax_2d_reg<9>, grid, block, cap_lds, st, heatmaps, w, multiplier, softmax, coords,
                            heatmaps_out);
     } else if (vec_ok && hw == kThreads * 4 * 4) {  // 64 x 64
-        hipLaunchKernelGGL(soft_argmax_2d_reg<4>, grid, block, 0, st, heatmaps, w, multiplier, softmax, coords,
+        hipLaunchKernelGGL(soft_argmax_2d_reg<4>, grid, block, cap_lds, st, heatmaps, w, multiplier, softmax, coords,
                            heatmaps_out);
     } else if (vec_ok && hw == kThreads * 4 * 16) {  // 128 x 128
-        hipLaunchKernelGGL(soft_argmax_2d_reg<16>, grid, block, 0, st, heatmaps, w, multiplier, softmax, coords,
+        hipLaunchKernelGGL(soft_argmax_2d_reg<16>, grid, block, cap_lds, st, heatmaps, w, multiplier, softmax, coords,
                            heatmaps_out);
     } else if (static_cast<size_t>(hw) * sizeof(float) <= 64 * 1024) {
         hipLaunchKernelGGL(soft_argmax_2d_any<true>, grid, block, static_cast<size_t>(hw) * sizeof(float), st,

@@ -6,10 +6,11 @@
 // volume is read once per frame instead of once per joint.
 // Pass 2 (finish): per (frame, volume) the records are combined (rescaled to the global max) into the
 // coordinates; when the normalised volumes are wanted the same kernel re-reads the volume and writes
-// exp(t - M) / S.  The host loop feeds pass 1 and pass 2 a few frames at a time so that the second read of a
-// volume is served by the Infinity Cache rather than HBM.
+// exp(t - M) / S.  (Feeding the two passes a few frames at a time so that the second read would hit the
+// Infinity Cache was measured slower than two full-batch launches: the small launches leave CUs idle.)
 //
-// HBM traffic per frame: J*N*4 (volumes) + N*12 (coordinates) [+ J*N*4 written] + J*12 bytes out.
+// Algorithmic bytes per frame: J*N*4 (volumes) + N*12 (coordinates) [+ J*N*4 written] + J*12 out; with the
+// write-back the volumes cross HBM a second time on the read side.
 #include <stdlib.h>
 
 #include "mvx_common.h"
@@ -261,16 +262,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_finish(const float* _
 // every CU busy when there are few frames.
 int pick_nv(int64_t n_frames, int64_t n_vox) {
     const int64_t blocks_long = n_frames * ((n_vox + 4095) / 4096);
-    return blocks_long >= 1024 ? 4 : 1;
-}
-
-int64_t chunk_budget_bytes() {
-    static int64_t budget = [] {
-        const char* e = getenv("MVX_SAM3D_CHUNK_MB");
-        const long mb = e != nullptr ? atol(e) : 0;
-        return static_cast<int64_t>(mb > 0 ? mb : 64) << 20;
-    }();
-    return budget;
+    return blocks_long >= 512 ? 4 : 1;
 }
 
 }  // namespace
@@ -314,44 +306,28 @@ extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volu
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partial = static_cast<double*>(workspace);
 
-    // With the write-back the volumes are read twice; a chunk of frames small enough to stay in the
-    // Infinity Cache between the two passes turns the second read into an on-die hit.
-    int64_t chunk = n_frames;
-    if (volumes_out != nullptr) {
-        chunk = chunk_budget_bytes() / (static_cast<int64_t>(n_volumes) * n_vox * 4);
-        if (chunk < 1) chunk = 1;
-    }
-    const int64_t max_blocks = 0x7fffffffLL;
-    if (chunk * bpf > max_blocks) chunk = max_blocks / bpf;
-    if (chunk * n_volumes * bpv > max_blocks) chunk = max_blocks / (static_cast<int64_t>(n_volumes) * bpv);
-    MVX_REQUIRE(chunk >= 1, MVX_ERR_UNSUPPORTED, "mvx_soft_argmax_3d: one frame exceeds the launch limits");
+    MVX_REQUIRE(n_frames * bpf <= 0x7fffffffLL && n_frames * n_volumes * bpv <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED,
+                "mvx_soft_argmax_3d: batch exceeds the launch limits");
 
-    for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
-        const int64_t nf = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
-        const float* v = volumes + f0 * n_volumes * n_vox;
-        const float* c = coords_volume != nullptr ? coords_volume + f0 * n_vox * 3 : nullptr;
-        double* p = partial + f0 * n_volumes * n_seg * kRecord;
-        const dim3 grid1(static_cast<unsigned>(nf * bpf)), block(kThreads);
-#define MVX_LAUNCH_PARTIAL(NV, VEC)                                                                                  \
-    hipLaunchKernelGGL((soft_argmax_3d_partial<NV, VEC>), grid1, block, 0, st, v, c, n_volumes, n_vox, g, n_seg, bpf, \
-                       multiplier, softmax, p)
-        if (nv == 4 && vec) MVX_LAUNCH_PARTIAL(4, true);
-        else if (nv == 4) MVX_LAUNCH_PARTIAL(4, false);
-        else if (vec) MVX_LAUNCH_PARTIAL(1, true);
-        else MVX_LAUNCH_PARTIAL(1, false);
+    const dim3 grid1(static_cast<unsigned>(n_frames * bpf)), block(kThreads);
+#define MVX_LAUNCH_PARTIAL(NV, VEC)                                                                              \
+    hipLaunchKernelGGL((soft_argmax_3d_partial<NV, VEC>), grid1, block, 0, st, volumes, coords_volume, n_volumes, \
+                       n_vox, g, n_seg, bpf, multiplier, softmax, partial)
+    if (nv == 4 && vec) MVX_LAUNCH_PARTIAL(4, true);
+    else if (nv == 4) MVX_LAUNCH_PARTIAL(4, false);
+    else if (vec) MVX_LAUNCH_PARTIAL(1, true);
+    else MVX_LAUNCH_PARTIAL(1, false);
 #undef MVX_LAUNCH_PARTIAL
-        MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (partial)");
-        const dim3 grid2(static_cast<unsigned>(nf * n_volumes * bpv));
-        float* o = out + f0 * n_volumes * 3;
-        float* vo = volumes_out != nullptr ? volumes_out + f0 * n_volumes * n_vox : nullptr;
-#define MVX_LAUNCH_FINISH(WRITE, VEC)                                                                              \
-    hipLaunchKernelGGL((soft_argmax_3d_finish<WRITE, VEC>), grid2, block, 0, st, v, n_vox, n_seg, bpv, multiplier, \
-                       mode, p, o, vo)
-        if (volumes_out != nullptr && vec) MVX_LAUNCH_FINISH(true, true);
-        else if (volumes_out != nullptr) MVX_LAUNCH_FINISH(true, false);
-        else MVX_LAUNCH_FINISH(false, false);
+    MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (partial)");
+
+    const dim3 grid2(static_cast<unsigned>(n_frames * n_volumes * bpv));
+#define MVX_LAUNCH_FINISH(WRITE, VEC)                                                                             \
+    hipLaunchKernelGGL((soft_argmax_3d_finish<WRITE, VEC>), grid2, block, 0, st, volumes, n_vox, n_seg, bpv, \
+                       multiplier, mode, partial, out, volumes_out)
+    if (volumes_out != nullptr && vec) MVX_LAUNCH_FINISH(true, true);
+    else if (volumes_out != nullptr) MVX_LAUNCH_FINISH(true, false);
+    else MVX_LAUNCH_FINISH(false, false);
 #undef MVX_LAUNCH_FINISH
-        MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (finish)");
-    }
+    MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (finish)");
     return MVX_OK;
 }

@@ -34,38 +34,45 @@ struct Tap {
     unsigned pixel;            // yb * W + xb, always inside the map
 };
 
-// Projects one voxel with P (3x4, row-major) and returns the bilinear taps with zero padding.
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+
+// Projects one voxel and returns its bilinear taps with zero padding.
 // The reference maps the projected pixel (x, y) = (u/z, v/z) through gx = 2(x/H - 0.5), gy = 2(y/W - 0.5)
 // (H for x and W for y) and grid_sample(align_corners=True): ix = (gx + 1)/2 * (W - 1) = x/H * (W - 1),
-// iy = y/W * (H - 1).  The position is evaluated in float64 and only the interpolation weights are rounded
-// to float32: the reference's float32 position carries about 1e-5 px of rounding noise, which would
-// otherwise be multiplied by the feature gradient.  A voxel with z <= 0 gets all-zero weights.
-__device__ __forceinline__ Tap project_tap(const float* __restrict__ P, float cx, float cy, float cz, int H, int W) {
-    const double X = cx, Y = cy, Z = cz;
-    const double u = fma(X, static_cast<double>(P[0]), fma(Y, static_cast<double>(P[1]), fma(Z, static_cast<double>(P[2]), static_cast<double>(P[3]))));
-    const double v = fma(X, static_cast<double>(P[4]), fma(Y, static_cast<double>(P[5]), fma(Z, static_cast<double>(P[6]), static_cast<double>(P[7]))));
-    const double z = fma(X, static_cast<double>(P[8]), fma(Y, static_cast<double>(P[9]), fma(Z, static_cast<double>(P[10]), static_cast<double>(P[11]))));
-    const bool behind = z <= 0.0;
-    const double rz = 1.0 / ((z == 0.0) ? 1.0 : z);
-    const double ixd = (u * rz) / static_cast<double>(H) * static_cast<double>(W - 1);
-    const double iyd = (v * rz) / static_cast<double>(W) * static_cast<double>(H - 1);
+// iy = y/W * (H - 1).  Here the camera Pd is float64 with rows 0 and 1 already multiplied by (W-1)/H and
+// (H-1)/W, so ix = u'/z, iy = v'/z; the position is evaluated in float64 and only the interpolation weights
+// are rounded to float32 (the reference's float32 position carries about 1e-5 px of rounding noise, which the
+// feature gradient would multiply).  1/z is v_rcp_f32 refined by two Newton steps in float64 (relative error
+// below 1e-15) instead of a float64 division.  A voxel with z <= 0 gets all-zero weights; `wscale`
+// multiplies the weights (log2 e for the softmax aggregation, which works in base 2).
+__device__ __forceinline__ Tap project_tap(const double* __restrict__ Pd, double X, double Y, double Z, int H, int W,
+                                           float wscale) {
+    const double u = fma(X, Pd[0], fma(Y, Pd[1], fma(Z, Pd[2], Pd[3])));
+    const double v = fma(X, Pd[4], fma(Y, Pd[5], fma(Z, Pd[6], Pd[7])));
+    const double z0 = fma(X, Pd[8], fma(Y, Pd[9], fma(Z, Pd[10], Pd[11])));
+    const bool behind = z0 <= 0.0;
+    const double z = (z0 == 0.0) ? 1.0 : z0;
+    double rz = static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(z)));
+    rz = fma(rz, fma(-z, rz, 1.0), rz);
+    rz = fma(rz, fma(-z, rz, 1.0), rz);
+    const double ixd = u * rz, iyd = v * rz;
     const double x0d = floor(ixd), y0d = floor(iyd);
     const float wx1 = static_cast<float>(ixd - x0d), wy1 = static_cast<float>(iyd - y0d);
     const float wx0 = static_cast<float>((x0d + 1.0) - ixd), wy0 = static_cast<float>((y0d + 1.0) - iyd);
-    const float ix = static_cast<float>(ixd), iy = static_cast<float>(iyd);
     const float x0f = static_cast<float>(x0d), y0f = static_cast<float>(y0d);
     // clamp before the conversion so that far-away or non-finite positions become "outside"
     const int x0 = static_cast<int>(fminf(fmaxf(x0f, -2.0f), static_cast<float>(W)));
     const int y0 = static_cast<int>(fminf(fmaxf(y0f, -2.0f), static_cast<float>(H)));
-    const bool finite = (ix - ix == 0.0f) && (iy - iy == 0.0f) && !behind;
+    const bool finite = (x0f - x0f == 0.0f) && (y0f - y0f == 0.0f) && !behind;
     const bool vx0 = finite && x0 >= 0 && x0 <= W - 1, vx1 = finite && x0 + 1 >= 0 && x0 + 1 <= W - 1;
     const bool vy0 = finite && y0 >= 0 && y0 <= H - 1, vy1 = finite && y0 + 1 >= 0 && y0 + 1 <= H - 1;
     const int xb = min(max(x0, 0), W - 2), yb = min(max(y0, 0), H - 2);
     // column xb holds tap x0 (if x0 == xb) or tap x0+1 (if x0 + 1 == xb, i.e. x0 == -1); likewise xb+1
     const float cxa = (vx0 && x0 == xb) ? wx0 : ((vx1 && x0 + 1 == xb) ? wx1 : 0.0f);
     const float cxb = (vx1 && x0 == xb) ? wx1 : ((vx0 && x0 == xb + 1) ? wx0 : 0.0f);
-    const float cya = (vy0 && y0 == yb) ? wy0 : ((vy1 && y0 + 1 == yb) ? wy1 : 0.0f);
-    const float cyb = (vy1 && y0 == yb) ? wy1 : ((vy0 && y0 == yb + 1) ? wy0 : 0.0f);
+    const float cya = ((vy0 && y0 == yb) ? wy0 : ((vy1 && y0 + 1 == yb) ? wy1 : 0.0f)) * wscale;
+    const float cyb = ((vy1 && y0 == yb) ? wy1 : ((vy0 && y0 == yb + 1) ? wy0 : 0.0f)) * wscale;
     Tap t;
     t.w00 = cxa * cya;
     t.w01 = cxb * cya;
@@ -75,7 +82,14 @@ __device__ __forceinline__ Tap project_tap(const float* __restrict__ P, float cx
     return t;
 }
 
-// Aggregation over views of four channels at a time.
+// Camera row r of a float32 3x4 matrix as float64, scaled for project_tap.
+__device__ __forceinline__ double camera_entry(const float* __restrict__ P, int i, double sx, double sy) {
+    const int r = i >> 2;
+    return static_cast<double>(P[i]) * (r == 0 ? sx : (r == 1 ? sy : 1.0));
+}
+
+// Aggregation over views of four channels at a time, for any number of views.  For the softmax the sampled
+// values arrive multiplied by log2 e (see project_tap) and the result is multiplied by ln 2.
 template <int AGG>
 struct Aggregator {
     float a[4], num[4], den[4];
@@ -98,9 +112,9 @@ struct Aggregator {
                 a[k] = fmaxf(a[k], val[k]);
             } else {
                 // online softmax over views with one exp per value: a = running max,
-                // num = sum val*exp(val - a), den = sum exp(val - a)
+                // num = sum val*2^(val - a), den = sum 2^(val - a)
                 const float d = val[k] - a[k];
-                const float r = exp_neg(-fabsf(d));
+                const float r = __builtin_amdgcn_exp2f(-fabsf(d));
                 const bool up = d > 0.0f;
                 const float keep = up ? r : 1.0f;  // rescale of what is already summed
                 const float e = up ? 1.0f : r;     // weight of the new value
@@ -110,7 +124,9 @@ struct Aggregator {
             }
         }
     }
-    __device__ __forceinline__ float result(int k) const { return AGG == MVX_AGG_SOFTMAX ? num[k] / den[k] : a[k]; }
+    __device__ __forceinline__ float result(int k) const {
+        return AGG == MVX_AGG_SOFTMAX ? num[k] * __builtin_amdgcn_rcpf(den[k]) * kLn2 : a[k];
+    }
 };
 
 __device__ __forceinline__ void sample4(const float* __restrict__ img, const Tap& t, int W, int Cp, int q,
@@ -156,14 +172,14 @@ __global__ __launch_bounds__(kThreads) void to_channel_last(const float* __restr
     }
 }
 
-// One lane per (voxel, channel quad).  feat_cl: channel-last maps of frames [f0, f0+nf).
+// One lane per (voxel, channel quad).  feat_cl: channel-last maps of the frames this launch covers.
 template <int AGG>
 __global__ __launch_bounds__(kThreads) void unproject_generic(const float* __restrict__ feat_cl,
                                                               const float* __restrict__ proj,
                                                               const float* __restrict__ coord,
                                                               const float* __restrict__ vconf, int64_t n_items,
                                                               int V, int C, int Cp, int H, int W, int64_t n_vox,
-                                                              float* __restrict__ vol) {
+                                                              double sx, double sy, float* __restrict__ vol) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
     if (idx >= n_items) return;
     const int Cq = Cp >> 2;
@@ -171,11 +187,14 @@ __global__ __launch_bounds__(kThreads) void unproject_generic(const float* __res
     const int64_t bn = idx / Cq;
     const int64_t b = bn / n_vox, n = bn - b * n_vox;
     const float* cp = coord + (b * n_vox + n) * 3;
-    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    const double X = cp[0], Y = cp[1], Z = cp[2];
     Aggregator<AGG> agg;
     agg.init();
     for (int v = 0; v < V; ++v) {
-        const Tap t = project_tap(proj + (b * V + v) * 12, cx, cy, cz, H, W);
+        double Pd[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Pd[i] = camera_entry(proj + (b * V + v) * 12, i, sx, sy);
+        const Tap t = project_tap(Pd, X, Y, Z, H, W, AGG == MVX_AGG_SOFTMAX ? kLog2e : 1.0f);
         float val[4], conf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         sample4(feat_cl + (b * V + v) * static_cast<size_t>(H) * W * Cp, t, W, Cp, q, val);
         if (AGG == MVX_AGG_CONF) {
@@ -195,18 +214,21 @@ __global__ __launch_bounds__(kThreads) void unproject_generic(const float* __res
 constexpr int kTile = 128;
 constexpr int kTileMaxViews = 16;
 
-template <int AGG>
+// FOUR: exactly four views, unrolled, with the view softmax evaluated exactly (max, then exp2); otherwise any
+// V <= kTileMaxViews with the online form.
+template <int AGG, bool FOUR>
 __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __restrict__ feat_cl,
                                                              const float* __restrict__ proj,
                                                              const float* __restrict__ coord,
                                                              const float* __restrict__ vconf, int V, int H, int W,
-                                                             int64_t n_vox, int tiles_per_frame,
+                                                             int64_t n_vox, int tiles_per_frame, double sx, double sy,
                                                              float* __restrict__ vol) {
     constexpr int C = 32;
     extern __shared__ __align__(16) unsigned char smem[];
-    float* out_t = reinterpret_cast<float*>(smem);                                 // [32][kTile], swizzled
-    float4* wts = reinterpret_cast<float4*>(smem + C * kTile * sizeof(float));     // [V][kTile]
-    unsigned* pix = reinterpret_cast<unsigned*>(wts + static_cast<size_t>(V) * kTile);  // [V][kTile]
+    float* out_t = reinterpret_cast<float*>(smem);                                       // [32][kTile], swizzled
+    float4* wts = reinterpret_cast<float4*>(smem + C * kTile * sizeof(float));           // [V][kTile]
+    unsigned* pix = reinterpret_cast<unsigned*>(wts + static_cast<size_t>(V) * kTile);   // [V][kTile]
+    double* cam = reinterpret_cast<double*>(pix + static_cast<size_t>(V) * kTile);       // [V][12]
 
     const int tid = threadIdx.x;
     const unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -214,45 +236,98 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
     const int64_t n0 = static_cast<int64_t>(work % tiles_per_frame) * kTile;
     const size_t img_stride = static_cast<size_t>(H) * W * C;
 
-    // phase A: taps of every (view, voxel) of the tile
-    for (int i = tid; i < V * kTile; i += kThreads) {
-        const int v = i / kTile, t = i - v * kTile;
+    // phase A: cameras to float64, then the taps of every (view, voxel) of the tile
+    if (tid < V * 12) cam[tid] = camera_entry(proj + b * V * 12 + (tid / 12) * 12, tid % 12, sx, sy);
+    __syncthreads();
+    {
+        const int t = tid & (kTile - 1);
         const float* cp = coord + (b * n_vox + n0 + t) * 3;
-        const Tap tap = project_tap(proj + (b * V + v) * 12, cp[0], cp[1], cp[2], H, W);
-        wts[i] = make_float4(tap.w00, tap.w01, tap.w10, tap.w11);
-        pix[i] = tap.pixel;
+        const double X = cp[0], Y = cp[1], Z = cp[2];
+        for (int v = tid / kTile; v < V; v += kThreads / kTile) {
+            const Tap tap = project_tap(cam + v * 12, X, Y, Z, H, W, AGG == MVX_AGG_SOFTMAX ? kLog2e : 1.0f);
+            wts[v * kTile + t] = make_float4(tap.w00, tap.w01, tap.w10, tap.w11);
+            pix[v * kTile + t] = tap.pixel;
+        }
     }
     __syncthreads();
 
     // phase B: 8 lanes per voxel, 4 channels per lane
     const int q = tid & 7;
     const float* fb = feat_cl + b * V * img_stride;
-#pragma unroll 2
-    for (int step = 0; step < kTile / 32; ++step) {
-        const int t = step * 32 + (tid >> 3);
-        Aggregator<AGG> agg;
-        agg.init();
-        for (int v = 0; v < V; ++v) {
-            const float4 w4 = wts[v * kTile + t];
-            Tap tap;
-            tap.w00 = w4.x;
-            tap.w01 = w4.y;
-            tap.w10 = w4.z;
-            tap.w11 = w4.w;
-            tap.pixel = pix[v * kTile + t];
-            float val[4], conf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            sample4(fb + v * img_stride, tap, W, C, q, val);
-            if (AGG == MVX_AGG_CONF) {
-                const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * V + v) * C + q * 4);
-                conf[0] = c4.x;
-                conf[1] = c4.y;
-                conf[2] = c4.z;
-                conf[3] = c4.w;
-            }
-            agg.add(val, conf);
-        }
+    if (FOUR) {
+        float cc[4][4];
+        if (AGG == MVX_AGG_CONF) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = agg.result(k);
+            for (int v = 0; v < 4; ++v) {
+                const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * 4 + v) * C + q * 4);
+                cc[v][0] = c4.x;
+                cc[v][1] = c4.y;
+                cc[v][2] = c4.z;
+                cc[v][3] = c4.w;
+            }
+        }
+        for (int step = 0; step < kTile / 32; ++step) {
+            const int t = step * 32 + (tid >> 3);
+            float val[4][4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 w4 = wts[v * kTile + t];
+                Tap tap;
+                tap.w00 = w4.x;
+                tap.w01 = w4.y;
+                tap.w10 = w4.z;
+                tap.w11 = w4.w;
+                tap.pixel = pix[v * kTile + t];
+                sample4(fb + v * img_stride, tap, W, C, q, val[v]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float r;
+                if (AGG == MVX_AGG_SUM) {
+                    r = ((val[0][k] + val[1][k]) + val[2][k]) + val[3][k];
+                } else if (AGG == MVX_AGG_CONF) {
+                    r = fmaf(val[3][k], cc[3][k], fmaf(val[2][k], cc[2][k], fmaf(val[1][k], cc[1][k], val[0][k] * cc[0][k])));
+                } else if (AGG == MVX_AGG_MAX) {
+                    r = fmaxf(fmaxf(val[0][k], val[1][k]), fmaxf(val[2][k], val[3][k]));
+                } else {
+                    const float m = fmaxf(fmaxf(val[0][k], val[1][k]), fmaxf(val[2][k], val[3][k]));
+                    const float e0 = __builtin_amdgcn_exp2f(val[0][k] - m), e1 = __builtin_amdgcn_exp2f(val[1][k] - m);
+                    const float e2 = __builtin_amdgcn_exp2f(val[2][k] - m), e3 = __builtin_amdgcn_exp2f(val[3][k] - m);
+                    const float den = (e0 + e1) + (e2 + e3);
+                    const float num = fmaf(e3, val[3][k], fmaf(e2, val[2][k], fmaf(e1, val[1][k], e0 * val[0][k])));
+                    r = num * __builtin_amdgcn_rcpf(den) * kLn2;
+                }
+                out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = r;
+            }
+        }
+    } else {
+#pragma unroll 2
+        for (int step = 0; step < kTile / 32; ++step) {
+            const int t = step * 32 + (tid >> 3);
+            Aggregator<AGG> agg;
+            agg.init();
+            for (int v = 0; v < V; ++v) {
+                const float4 w4 = wts[v * kTile + t];
+                Tap tap;
+                tap.w00 = w4.x;
+                tap.w01 = w4.y;
+                tap.w10 = w4.z;
+                tap.w11 = w4.w;
+                tap.pixel = pix[v * kTile + t];
+                float val[4], conf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                sample4(fb + v * img_stride, tap, W, C, q, val);
+                if (AGG == MVX_AGG_CONF) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * V + v) * C + q * 4);
+                    conf[0] = c4.x;
+                    conf[1] = c4.y;
+                    conf[2] = c4.z;
+                    conf[3] = c4.w;
+                }
+                agg.add(val, conf);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = agg.result(k);
+        }
     }
     __syncthreads();
 
@@ -303,7 +378,9 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
     const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
     const bool tiled = (C == 32) && (V <= kTileMaxViews) && (n_voxels % kTile == 0) && aligned16(volumes) &&
                        (aggregation != MVX_AGG_CONF || aligned16(vol_conf));
-    const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V) * kTile * 20;
+    const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V) * kTile * 20 + static_cast<size_t>(V) * 12 * 8;
+    const double sx = static_cast<double>(w - 1) / static_cast<double>(h);  // ix = x / H * (W - 1)
+    const double sy = static_cast<double>(h - 1) / static_cast<double>(w);  // iy = y / W * (H - 1)
 
     for (int64_t f0 = 0; f0 < n_frames; f0 += kChunkFrames) {
         const int64_t nf = (n_frames - f0 < kChunkFrames) ? n_frames - f0 : kChunkFrames;
@@ -320,9 +397,13 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
             const int64_t tiles = n_voxels / kTile;
             MVX_REQUIRE(nf * tiles <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: voxel grid too large");
             const dim3 grid(static_cast<unsigned>(nf * tiles));
-#define MVX_LAUNCH_TILE(AGG)                                                                                       \
-    hipLaunchKernelGGL(unproject_tile32<AGG>, grid, dim3(kThreads), smem, st, feat_cl, pj, cd, vc, V, h, w, n_voxels, \
-                       static_cast<int>(tiles), vo)
+#define MVX_LAUNCH_TILE(AGG)                                                                                        \
+    if (V == 4)                                                                                                     \
+        hipLaunchKernelGGL((unproject_tile32<AGG, true>), grid, dim3(kThreads), smem, st, feat_cl, pj, cd, vc, V, h, w, \
+                           n_voxels, static_cast<int>(tiles), sx, sy, vo);                                          \
+    else                                                                                                            \
+        hipLaunchKernelGGL((unproject_tile32<AGG, false>), grid, dim3(kThreads), smem, st, feat_cl, pj, cd, vc, V, h, \
+                           w, n_voxels, static_cast<int>(tiles), sx, sy, vo)
             switch (aggregation) {
                 case MVX_AGG_SUM: MVX_LAUNCH_TILE(MVX_AGG_SUM); break;
                 case MVX_AGG_CONF: MVX_LAUNCH_TILE(MVX_AGG_CONF); break;
@@ -337,7 +418,7 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
             const dim3 grid(static_cast<unsigned>(blocks));
 #define MVX_LAUNCH_GENERIC(AGG)                                                                                  \
     hipLaunchKernelGGL(unproject_generic<AGG>, grid, dim3(kThreads), 0, st, feat_cl, pj, cd, vc, n_items, V, C, Cp, h, \
-                       w, n_voxels, vo)
+                       w, n_voxels, sx, sy, vo)
             switch (aggregation) {
                 case MVX_AGG_SUM: MVX_LAUNCH_GENERIC(MVX_AGG_SUM); break;
                 case MVX_AGG_CONF: MVX_LAUNCH_GENERIC(MVX_AGG_CONF); break;
