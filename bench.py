@@ -60,6 +60,18 @@ class EventTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
 
 
+def measured_traffic(kernel, frames, views, writeback):
+    """HBM bytes per launch of `kernel` from the rocprofv3 counter passes stored under profiles/ (collected
+    with the same launch shape in a separate profiled run: counters cannot be read from inside this process)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[kernel]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    if (rec["frames"], rec["views"], rec["heatmap_writeback"]) != (frames, views, writeback):
+        return None, None
+    return rec["hbm_bytes_per_launch"], rec["source"]
+
+
 def cpu_baseline_algebraic(n_views, sample_frames):
     """The torch-CPU port (oracle/torch_port.py) on a bounded sample of the same workload, host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -139,6 +151,7 @@ def run_algebraic(args, dev, rank, world, n_views=4, frames=4096, writeback=True
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"], roof["traffic_source"] = measured_traffic("soft_argmax_2d_reg<9>", frames, v, writeback)
     extra = {"dlt_kernel_ms": k2.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err)}
     cfg = {"workload": "algebraic: soft-argmax 2D + confidence-weighted DLT, %d frames/GPU x %d views x 17 joints, 96x96 heatmaps"
                        % (frames, v), "frames_per_gpu": frames, "views": v, "joints": j, "heatmap_writeback": writeback,
