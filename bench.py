@@ -133,7 +133,7 @@ def run_algebraic(args, dev, rank, world, n_views=4, frames=4096, writeback=True
         if rc != 0:
             raise RuntimeError("mvx call failed: %s" % lib.mvx_last_error().decode())
         if world > 1:
-            return sharding.all_gather_keypoints(kp3d, frames * world)
+            return gather(kp3d, frames * world)
         return kp3d
 
     # the drop-in class path gives the same numbers as the preallocated calls
@@ -176,7 +176,7 @@ def run_volumetric(args, dev, rank, world, frames=64):
             kp, _ = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
         del u
         if world > 1:
-            return sharding.all_gather_keypoints(kp, frames * world)
+            return gather(kp, frames * world)
         return kp
 
     step(False)
@@ -194,6 +194,13 @@ def run_volumetric(args, dev, rank, world, frames=64):
     return ms, frames, roof, cfg, extra
 
 
+def gather(local_kp, total_frames):
+    """All-gather of the keypoints: RCCL on device tensors; in the single-GPU rehearsal, gloo on host copies."""
+    if dist.get_backend() == "gloo":
+        return sharding.all_gather_keypoints(local_kp.cpu(), total_frames).to(local_kp.device)
+    return sharding.all_gather_keypoints(local_kp, total_frames)
+
+
 def timed_loop(step, args, dev, world):
     for _ in range(args.warmup):
         step(False)
@@ -208,7 +215,7 @@ def timed_loop(step, args, dev, world):
     torch.cuda.synchronize(dev)
     secs = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([secs], dtype=torch.float64, device=dev)
+        t = torch.tensor([secs], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
     return secs * 1e3 / args.steps
@@ -245,11 +252,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MVX_BENCH_REHEARSAL=1 rehearses the multi-rank path on a single GPU: every rank uses cuda:0 and the
+    # collectives run over gloo on host copies (RCCL needs one device per rank).  Not a measurement mode.
+    rehearsal = os.environ.get("MVX_BENCH_REHEARSAL") == "1"
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://")
+        dist.init_process_group("gloo" if rehearsal else "nccl", init_method="env://")
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     _cabi.load()  # fails loudly if libmvx.so was not built
 
