@@ -16,24 +16,29 @@ namespace mvx {
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
+constexpr int kThreads = 256;  // block size of the any-shape kernel
 
+template <int WAVES>
 struct BlockReduce {
-    float m[kWaves];
-    double s[kWaves][3];
+    float m[WAVES];
+    double s[WAVES][3];
 };
 
 // Block-wide max of one float per thread; every thread gets the result.
-__device__ __forceinline__ float block_max(float v, BlockReduce& red) {
+template <int WAVES>
+__device__ __forceinline__ float block_max(float v, BlockReduce<WAVES>& red) {
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) red.m[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(red.m[0], red.m[1]), fmaxf(red.m[2], red.m[3]));
+    float m = red.m[0];
+#pragma unroll
+    for (int i = 1; i < WAVES; ++i) m = fmaxf(m, red.m[i]);
+    return m;
 }
 
 // Block-wide sums of three doubles per thread; every thread gets the results.
-__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, BlockReduce& red) {
+template <int WAVES>
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, BlockReduce<WAVES>& red) {
     a = wave_sum(a);
     b = wave_sum(b);
     c = wave_sum(c);
@@ -43,9 +48,15 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, Bloc
         red.s[threadIdx.x >> 6][2] = c;
     }
     __syncthreads();
-    a = (red.s[0][0] + red.s[1][0]) + (red.s[2][0] + red.s[3][0]);
-    b = (red.s[0][1] + red.s[1][1]) + (red.s[2][1] + red.s[3][1]);
-    c = (red.s[0][2] + red.s[1][2]) + (red.s[2][2] + red.s[3][2]);
+    a = red.s[0][0];
+    b = red.s[0][1];
+    c = red.s[0][2];
+#pragma unroll
+    for (int i = 1; i < WAVES; ++i) {
+        a += red.s[i][0];
+        b += red.s[i][1];
+        c += red.s[i][2];
+    }
 }
 
 // Adds the four elements of one float4 (same row, columns col..col+3) to the float64 sums.
@@ -76,12 +87,13 @@ __device__ __forceinline__ void store_f4(float4* p, const float4& v, bool nt) {
     }
 }
 
-// h*w == 256*4*NV and w % 4 == 0: the map lives in NV float4 registers per thread.
-template <int NV>
-__global__ __launch_bounds__(kThreads) void soft_argmax_2d_reg(const float* __restrict__ hm, int w, float mult,
-                                                                int softmax, float* __restrict__ coords,
-                                                                float* __restrict__ out) {
-    __shared__ BlockReduce red;
+// h*w == THREADS*4*NV and w % 4 == 0: the map lives in NV float4 registers per thread.
+template <int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void soft_argmax_2d_reg(const float* __restrict__ hm, int w, float mult,
+                                                               int softmax, float* __restrict__ coords,
+                                                               float* __restrict__ out) {
+    constexpr int kThreads = THREADS;
+    __shared__ BlockReduce<THREADS / 64> red;
     const int tid = threadIdx.x;
     const size_t map = blockIdx.x;
     constexpr int HW = kThreads * 4 * NV;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_2d_any(const float* __re
                                                                 int softmax, float* __restrict__ coords,
                                                                 float* __restrict__ out) {
     extern __shared__ __align__(16) float tile[];
-    __shared__ BlockReduce red;
+    __shared__ BlockReduce<kThreads / 64> red;
     const int tid = threadIdx.x;
     const size_t map = blockIdx.x;
     const int hw = h * w;
@@ -245,15 +257,16 @@ extern "C" int mvx_soft_argmax_2d(const float* heatmaps, int64_t n_maps, int h, 
     }
     if (per_cu < 1) per_cu = 1;
     const size_t cap_lds = per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
-    if (vec_ok && hw == kThreads * 4 * 9) {  // 96 x 96
-        hipLaunchKernelGGL(soft_argmax_2d_reg<9>, grid, block, cap_lds, st, heatmaps, w, multiplier, softmax, coords,
-                           heatmaps_out);
-    } else if (vec_ok && hw == kThreads * 4 * 4) {  // 64 x 64
-        hipLaunchKernelGGL(soft_argmax_2d_reg<4>, grid, block, cap_lds, st, heatmaps, w, multiplier, softmax, coords,
-                           heatmaps_out);
-    } else if (vec_ok && hw == kThreads * 4 * 16) {  // 128 x 128
-        hipLaunchKernelGGL(soft_argmax_2d_reg<16>, grid, block, cap_lds, st, heatmaps, w, multiplier, softmax, coords,
-                           heatmaps_out);
+    // (256, 384, 576 and 768 threads per map were measured within 1 % of each other at the same residency.)
+    if (vec_ok && hw == 256 * 4 * 9) {  // 96 x 96
+        hipLaunchKernelGGL((soft_argmax_2d_reg<256, 9>), grid, block, cap_lds, st, heatmaps, w, multiplier, softmax,
+                           coords, heatmaps_out);
+    } else if (vec_ok && hw == 256 * 4 * 4) {  // 64 x 64
+        hipLaunchKernelGGL((soft_argmax_2d_reg<256, 4>), grid, block, cap_lds, st, heatmaps, w, multiplier, softmax,
+                           coords, heatmaps_out);
+    } else if (vec_ok && hw == 256 * 4 * 16) {  // 128 x 128
+        hipLaunchKernelGGL((soft_argmax_2d_reg<256, 16>), grid, block, cap_lds, st, heatmaps, w, multiplier, softmax,
+                           coords, heatmaps_out);
     } else if (static_cast<size_t>(hw) * sizeof(float) <= 64 * 1024) {
         hipLaunchKernelGGL(soft_argmax_2d_any<true>, grid, block, static_cast<size_t>(hw) * sizeof(float), st,
                            heatmaps, h, w, multiplier, softmax, coords, heatmaps_out);
