@@ -96,16 +96,16 @@ int mvx_project_points(const float* proj, const float* points, int64_t n_points,
  * Replaces mvn/utils/op.py:99-166 (unproject_heatmaps).
  * features   [n_frames][n_views][n_channels][h][w]
  * proj       [n_frames][n_views][3][4]              projection to feature-map pixels
- * coords     [n_frames][n_voxels][3]                world position of every voxel (n_voxels = X*Y*Z)
+ * coords     [n_frames][vx][vy][vz][3]              world position of every voxel
  * vol_conf   [n_frames][n_views][n_channels]        MVX_AGG_CONF only, else may be NULL
- * volumes    [n_frames][n_channels][n_voxels]
+ * volumes    [n_frames][n_channels][vx][vy][vz]
  * workspace  mvx_unproject_workspace_bytes() bytes of device memory, 256-byte aligned (channel-last copy of
  *            the feature maps)
  */
 size_t mvx_unproject_workspace_bytes(int64_t n_frames, int n_views, int n_channels, int h, int w);
 int mvx_unproject(const float* features, const float* proj, const float* coords, const float* vol_conf,
-                  int64_t n_frames, int n_views, int n_channels, int h, int w, int64_t n_voxels, int aggregation,
-                  float* volumes, void* workspace, size_t workspace_bytes, void* stream);
+                  int64_t n_frames, int n_views, int n_channels, int h, int w, int vx, int vy, int vz,
+                  int aggregation, float* volumes, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Soft-argmax over voxel grids.

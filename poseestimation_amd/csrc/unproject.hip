@@ -19,7 +19,16 @@
 //
 // Step 2, generic kernel (any C, V, grid): one lane per (voxel, 4 channels), no LDS, direct stores.
 //
+// Measured on MI355X (8 frames per launch, V = 4): the tile kernel is bound by the vector-memory return path
+// (64 B/clk per CU; 512 B of taps per voxel and view whether or not the lines hit in L1), at about 21 us per
+// frame against a 6.6 us HBM floor.  A variant that fed the taps from an LDS patch staged per view and 2x2x32
+// tile was measured slower and is not kept (its stage / sample phases serialise at 2-3 workgroups per CU:
+// 3.0 ms against 1.6 ms for 64 frames); taps read from LDS with no staging cost bound what such a design
+// could reach at about 0.9-1.1 ms.
+//
 // HBM traffic per frame: V*C*h*w*4 (features) + N*12 (coordinates) + C*N*4 (volume written).
+#include <stdlib.h>
+
 #include "mvx_common.h"
 
 namespace mvx {
@@ -353,12 +362,13 @@ extern "C" size_t mvx_unproject_workspace_bytes(int64_t n_frames, int n_views, i
 }
 
 extern "C" int mvx_unproject(const float* features, const float* proj, const float* coords, const float* vol_conf,
-                             int64_t n_frames, int n_views, int n_channels, int h, int w, int64_t n_voxels,
+                             int64_t n_frames, int n_views, int n_channels, int h, int w, int vx, int vy, int vz,
                              int aggregation, float* volumes, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace mvx;
-    MVX_REQUIRE(n_frames >= 0 && n_views > 0 && n_channels > 0 && h >= 2 && w >= 2 && n_voxels >= 0,
-                MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: bad shape n_frames=%lld n_views=%d n_channels=%d h=%d w=%d n_voxels=%lld",
-                (long long)n_frames, n_views, n_channels, h, w, (long long)n_voxels);
+    MVX_REQUIRE(n_frames >= 0 && n_views > 0 && n_channels > 0 && h >= 2 && w >= 2 && vx >= 0 && vy >= 0 && vz >= 0,
+                MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: bad shape n_frames=%lld n_views=%d n_channels=%d h=%d w=%d grid=%dx%dx%d",
+                (long long)n_frames, n_views, n_channels, h, w, vx, vy, vz);
+    const int64_t n_voxels = static_cast<int64_t>(vx) * vy * vz;
     MVX_REQUIRE(aggregation >= MVX_AGG_SUM && aggregation <= MVX_AGG_SOFTMAX, MVX_ERR_INVALID_ARGUMENT,
                 "mvx_unproject: unknown aggregation %d", aggregation);
     if (n_frames == 0 || n_voxels == 0) return MVX_OK;
@@ -378,6 +388,8 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
     const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
     const bool tiled = (C == 32) && (V <= kTileMaxViews) && (n_voxels % kTile == 0) && aligned16(volumes) &&
                        (aggregation != MVX_AGG_CONF || aligned16(vol_conf));
+    const char* pe = getenv("MVX_UNPROJ_PATH");  // testing knob: "generic" forces the generic kernel
+    const bool force_generic = pe != nullptr && pe[0] == 'g';
     const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V) * kTile * 20 + static_cast<size_t>(V) * 12 * 8;
     const double sx = static_cast<double>(w - 1) / static_cast<double>(h);  // ix = x / H * (W - 1)
     const double sy = static_cast<double>(h - 1) / static_cast<double>(w);  // iy = y / W * (H - 1)
@@ -393,7 +405,7 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
         const float* cd = coords + f0 * n_voxels * 3;
         const float* vc = vol_conf != nullptr ? vol_conf + f0 * V * C : nullptr;
         float* vo = volumes + f0 * C * n_voxels;
-        if (tiled) {
+        if (tiled && !force_generic) {
             const int64_t tiles = n_voxels / kTile;
             MVX_REQUIRE(nf * tiles <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: voxel grid too large");
             const dim3 grid(static_cast<unsigned>(nf * tiles));

@@ -104,7 +104,6 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
     if tuple(proj.shape) != (b, v, 3, 4) or cv.shape[0] != b:
         raise ValueError("proj_matricies must be %s and coord_volumes batch %d" % ((b, v, 3, 4), b))
     vshape = tuple(cv.shape[1:4])
-    n_vox = vshape[0] * vshape[1] * vshape[2]
     vc = None
     if agg == _cabi.AGG_CONF:
         if vol_confidences is None:
@@ -117,8 +116,9 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
     ws_bytes = lib.mvx_unproject_workspace_bytes(b, v, c, h, w)
     ws = torch.empty((max(ws_bytes, 16) + 15) // 16 * 4, dtype=torch.float32, device=feats.device)
     with torch.cuda.device(feats.device):
-        st = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c, h, w, n_vox,
-                               agg, _cabi.ptr(volumes), _cabi.ptr(ws), ws.numel() * 4, _cabi.stream(feats.device))
+        st = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c, h, w,
+                               vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(volumes), _cabi.ptr(ws),
+                               ws.numel() * 4, _cabi.stream(feats.device))
     _cabi.check(st, "mvx_unproject")
     return volumes
 

@@ -209,15 +209,30 @@ def test_unproject_full_size_tile_kernel(method):
     assert np.abs(out.reshape(32, -1)[:, sub] - ref).max() < UNPROJ_TOL
 
 
-def test_unproject_tile_and_generic_kernels_agree():
-    """The tile kernel (C = 32, voxels % 128 == 0) and the generic kernel on the same maps."""
-    case = synth.volumetric_case(21, 2, 3, volume_size=16, with_volumes=False)
+@pytest.mark.parametrize("side,views", [(2500.0, 4), (2500.0, 3), (9000.0, 4), (30000.0, 2)])
+def test_unproject_kernel_paths_agree(side, views, monkeypatch):
+    """The tile kernel (C = 32, voxels % 128 == 0) and the generic kernel on the same maps.  A 9 m cuboid has
+    tiles with voxels outside every map; at 30 m whole tiles see no view at all."""
+    case = synth.volumetric_case(21, 2, views, volume_size=32, cuboid_side=side, with_volumes=False)
     feats, proj, coord, vconf = (to_dev(case[k]) for k in ("features", "proj", "coord_volumes", "vol_confidences"))
     for method in ("sum", "conf", "max", "softmax"):
-        tiled = op.unproject_heatmaps(feats, proj, coord, method, vconf)                     # 4096 voxels: tile kernel
-        cut = coord[:, :, :, :15].contiguous()                                                # 3840 voxels: generic
-        generic = op.unproject_heatmaps(feats, proj, cut, method, vconf)
-        assert torch.allclose(tiled[:, :, :, :, :15], generic, rtol=0, atol=2e-6)
+        outs = {}
+        for path in ("tile", "generic"):
+            monkeypatch.setenv("MVX_UNPROJ_PATH", path)
+            outs[path] = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+        assert torch.allclose(outs["tile"], outs["generic"], rtol=0, atol=2e-6)
+        if method == "softmax":
+            sub = np.arange(0, 32 ** 3, 97)
+            ref = orc.unproject_heatmaps(case["features"], case["proj"], case["coord_volumes"], method,
+                                         case["vol_confidences"], voxel_subset=sub)
+            got = outs["tile"].reshape(2, 32, -1)[:, :, sub].cpu().numpy()
+            assert np.abs(got - ref).max() < UNPROJ_TOL
+    # grids the tile kernel does not take (voxel count not a multiple of 128) go to the generic kernel
+    monkeypatch.delenv("MVX_UNPROJ_PATH")
+    cut = coord[:, :31, :, :15].contiguous()
+    generic = op.unproject_heatmaps(feats, proj, cut, "softmax", vconf)
+    full = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
+    assert torch.allclose(full[:, :, :31, :, :15], generic, rtol=0, atol=2e-6)
 
 
 def test_unproject_sum_is_linear_at_batch_size():

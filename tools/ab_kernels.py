@@ -78,7 +78,7 @@ def k3(rounds):
     f, p, c, vc = case["features"], case["proj"], case["coord_volumes"], case["vol_confidences"]
     for method in ("softmax", "conf", "sum", "max"):
         print("--", method)
-        time_variants(lambda: (op.unproject_heatmaps(f, p, c, method, vc),), "MVX_UNUSED", [0], rounds, inner=2)
+        time_variants(lambda: (op.unproject_heatmaps(f, p, c, method, vc),), "MVX_UNPROJ_PATH", ["tile", "generic"], rounds, inner=2)
 
 
 def k4(rounds):
