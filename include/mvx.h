@@ -84,6 +84,19 @@ int mvx_algebraic_glue_dlt(const float* proj, const float* points_hm, const floa
                            float* conf_norm_out, float* out, void* stream);
 
 /*
+ * Everything AlgebraicTriangulationNet.forward does after the backbone (mvn/models/triangulation.py:189-220)
+ * behind one call: mvx_soft_argmax_2d on the [n_frames*n_views*n_joints] heatmaps, then mvx_algebraic_glue_dlt.
+ * heatmaps             [n_frames][n_views][n_joints][h][w]   raw backbone output
+ * heatmaps_out         same shape, or NULL to skip the write of the normalised maps
+ * points_hm_workspace  [n_frames][n_views][n_joints][2]      receives the heatmap-pixel keypoints
+ * other arguments as in the two calls it stands for.
+ */
+int mvx_algebraic_forward(const float* heatmaps, const float* conf_raw, const float* proj, int64_t n_frames,
+                          int n_views, int n_joints, int h, int w, float multiplier, int softmax, float scale_x,
+                          float scale_y, float* heatmaps_out, float* points_img_out, float* conf_norm_out,
+                          float* out, float* points_hm_workspace, void* stream);
+
+/*
  * Projects n_points 3-D points with one 3x4 matrix.  Replaces mvn/utils/multiview.py:91-112
  * (project_3d_points_to_image_plane_without_distortion) for device tensors.
  * out [n_points][2] if to_euclidean != 0 (divided by the third component), else [n_points][3].

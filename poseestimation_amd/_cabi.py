@@ -25,6 +25,8 @@ SIGNATURES = {
     "mvx_soft_argmax_2d": (_int, [_vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp]),
     "mvx_triangulate_dlt": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
     "mvx_algebraic_glue_dlt": (_int, [_vp, _vp, _vp, _i64, _int, _int, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "mvx_algebraic_forward": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _f32, _f32, _vp, _vp, _vp,
+                                     _vp, _vp, _vp]),
     "mvx_project_points": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "mvx_unproject_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "mvx_unproject": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _sz,

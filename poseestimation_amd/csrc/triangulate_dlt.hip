@@ -4,7 +4,8 @@
 // (A = fl(fl(fl(P[2]*x) - P[0:2]) * c)), its Gram matrix A^T A (10 unique entries) is accumulated in float64
 // registers (products of two float32 values are exact in float64), and the eigenvector of the smallest
 // eigenvalue -- the right singular vector of A's smallest singular value -- comes from cyclic Jacobi
-// rotations on the 4x4 symmetric matrix, all in registers with compile-time indices.
+// rotations on the 4x4 symmetric matrix, all in registers with compile-time indices (sweeps repeat until every
+// off-diagonal entry is below 1e-18 of the geometric mean of its diagonal neighbours).
 // HBM traffic per point: 48*V (P, shared by the joints of a frame) + 8*V (points) + 4*V (conf) + 12 bytes out.
 #include "mvx_common.h"
 
@@ -15,15 +16,41 @@ namespace {
 constexpr int kThreads = 128;
 constexpr int kMaxSweeps = 16;
 
+// 1/x and 1/sqrt(x) to float64 accuracy from the hardware estimates (v_rcp_f64 / v_rsq_f64, about 2^-26 relative
+// error, refined by two Newton steps each): a much shorter dependent chain than the IEEE division and square
+// root routines, which matters because one lane walks 6 rotations x several sweeps serially.
+__device__ __forceinline__ double rcp_refined(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ double rsqrt_refined(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x, y * y, 1.5);
+    y = y * fma(-0.5 * x, y * y, 1.5);
+    return y;
+}
+
 // One Jacobi rotation annihilating a[P][Q] (P < Q); a is kept full and symmetric, v accumulates the
-// rotations (columns of v are the eigenvectors).
+// rotations (columns of v are the eigenvectors).  t = tan(angle) is the smaller root of t^2 + 2 t theta - 1 = 0,
+// theta = (a_qq - a_pp) / (2 a_pq); for |theta| beyond 1e100 the square would overflow and t = 1 / (2 theta).
 template <int P, int Q>
 __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][4]) {
     const double apq = a[P][Q];
     if (apq == 0.0) return;
-    const double theta = (a[Q][Q] - a[P][P]) / (2.0 * apq);
-    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-    const double c = 1.0 / sqrt(fma(t, t, 1.0));
+    const double theta = (a[Q][Q] - a[P][P]) * 0.5 * rcp_refined(apq);
+    const double ath = fabs(theta);
+    double t;
+    if (ath < 1e100) {
+        const double x = fma(theta, theta, 1.0);
+        t = rcp_refined(ath + x * rsqrt_refined(x));
+    } else {
+        t = 0.5 * rcp_refined(ath);  // also the limit for theta = inf (t = 0); NaN falls through to the check below
+    }
+    t = theta >= 0.0 ? t : -t;
+    if (!(t == t)) return;
+    const double c = rsqrt_refined(fma(t, t, 1.0));
     const double s = t * c;
     a[P][P] = fma(-t, apq, a[P][P]);
     a[Q][Q] = fma(t, apq, a[Q][Q]);
@@ -226,4 +253,22 @@ extern "C" int mvx_project_points(const float* proj, const float* points, int64_
                        static_cast<hipStream_t>(stream), proj, points, n_points, to_euclidean, out);
     MVX_CHECK_LAUNCH("mvx_project_points");
     return MVX_OK;
+}
+
+extern "C" int mvx_algebraic_forward(const float* heatmaps, const float* conf_raw, const float* proj, int64_t n_frames,
+                                     int n_views, int n_joints, int h, int w, float multiplier, int softmax,
+                                     float scale_x, float scale_y, float* heatmaps_out, float* points_img_out,
+                                     float* conf_norm_out, float* out, float* points_hm_workspace, void* stream) {
+    using namespace mvx;
+    MVX_REQUIRE(n_frames >= 0 && n_views > 0 && n_joints >= 0, MVX_ERR_INVALID_ARGUMENT,
+                "mvx_algebraic_forward: bad shape n_frames=%lld n_views=%d n_joints=%d", (long long)n_frames, n_views,
+                n_joints);
+    if (n_frames == 0 || n_joints == 0) return MVX_OK;
+    MVX_REQUIRE(points_hm_workspace != nullptr, MVX_ERR_INVALID_ARGUMENT,
+                "mvx_algebraic_forward: null points_hm_workspace");
+    const int rc = mvx_soft_argmax_2d(heatmaps, n_frames * n_views * n_joints, h, w, multiplier, softmax,
+                                      points_hm_workspace, heatmaps_out, stream);
+    if (rc != MVX_OK) return rc;
+    return mvx_algebraic_glue_dlt(proj, points_hm_workspace, conf_raw, n_frames, n_views, n_joints, scale_x, scale_y,
+                                  points_img_out, conf_norm_out, out, stream);
 }

@@ -61,29 +61,31 @@ class AlgebraicTriangulationNet(nn.Module):
 
     def triangulate_from_heatmaps(self, heatmaps, alg_confidences, proj_matricies, image_shape):
         """Everything after the backbone: soft-argmax (multiplier folded in), confidence normalisation,
-        keypoint upscale and DLT; two kernel launches.
+        keypoint upscale and DLT; one C-ABI call, two kernel launches.
 
         heatmaps (B, V, J, h, w) raw backbone output; alg_confidences (B, V, J); proj_matricies (B, V, 3, 4)
         for image pixels; image_shape (H, W).  Returns (keypoints_3d (B, J, 3), keypoints_2d (B, V, J, 2) in
         image pixels, normalised heatmaps (B, V, J, h, w), confidences (B, V, J))."""
         hm = _cabi.device_f32(heatmaps, "heatmaps")
         b, v, j, h, w = hm.shape
-        kp_hm, hm_norm = op.integrate_tensor_2d(hm.view(b * v, j, h, w), self.heatmap_softmax,
-                                                multiplier=self.heatmap_multiplier)
         conf = _cabi.device_f32(alg_confidences, "alg_confidences").reshape(b, v, j)
         proj = _cabi.device_f32(proj_matricies, "proj_matricies")
         if tuple(proj.shape) != (b, v, 3, 4):
             raise ValueError("proj_matricies must have shape %s, got %s" % ((b, v, 3, 4), tuple(proj.shape)))
-        kp_img = torch.empty((b, v, j, 2), dtype=torch.float32, device=hm.device)
-        conf_norm = torch.empty((b, v, j), dtype=torch.float32, device=hm.device)
-        kp3d = torch.zeros((b, j, 3), dtype=torch.float32, device=hm.device)
+        hm_norm = torch.empty_like(hm)
+        # one allocation for the small outputs: heatmap-pixel keypoints, image-pixel keypoints, confidences, joints
+        n2, n1, n3 = b * v * j * 2, b * v * j, b * j * 3
+        small = torch.empty(2 * n2 + n1 + n3, dtype=torch.float32, device=hm.device)
+        kp_hm, kp_img = small[:n2], small[n2:2 * n2].view(b, v, j, 2)
+        conf_norm, kp3d = small[2 * n2:2 * n2 + n1].view(b, v, j), small[2 * n2 + n1:].view(b, j, 3)
         with torch.cuda.device(hm.device):
-            st = _cabi.load().mvx_algebraic_glue_dlt(
-                _cabi.ptr(proj), _cabi.ptr(kp_hm), _cabi.ptr(conf), b, v, j, float(image_shape[1] / w),
-                float(image_shape[0] / h), _cabi.ptr(kp_img), _cabi.ptr(conf_norm), _cabi.ptr(kp3d),
+            st = _cabi.load().mvx_algebraic_forward(
+                _cabi.ptr(hm), _cabi.ptr(conf), _cabi.ptr(proj), b, v, j, h, w, float(self.heatmap_multiplier),
+                int(bool(self.heatmap_softmax)), float(image_shape[1] / w), float(image_shape[0] / h),
+                _cabi.ptr(hm_norm), _cabi.ptr(kp_img), _cabi.ptr(conf_norm), _cabi.ptr(kp3d), _cabi.ptr(kp_hm),
                 _cabi.stream(hm.device))
-        _cabi.check(st, "mvx_algebraic_glue_dlt")
-        return kp3d, kp_img, hm_norm.view(b, v, j, h, w), conf_norm
+        _cabi.check(st, "mvx_algebraic_forward")
+        return kp3d, kp_img, hm_norm, conf_norm
 
     def forward(self, images, proj_matricies, batch):
         device = images.device
