@@ -139,6 +139,22 @@ int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t
                        int sy, int sz, float multiplier, int softmax, float* out, float* volumes_out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Coordinate volumes of VolumetricTriangulationNet.forward: replaces the per-frame meshgrid / scale / rotate
+ * loop of mvn/models/triangulation.py:341-385 (and mvn/utils/volumetric.py:102-114) with one launch.
+ * For frame b and voxel (i0, i1, i2):  g = position[b] + step * (i0, i1, i2);  out = rotation[b] . (g - center[b])
+ * + center[b], every step in float32 in that order (bit-identical to the reference when rotation is the
+ * identity).  swap_yz_flip != 0 applies the reference's CMU-to-Human3.6M transfer (axes 1 and 2 swapped, new
+ * axis 1 reversed; needs s1 == s2).
+ * position  [n_frames][3]     minimum corner of the cuboid
+ * center    [n_frames][3]     rotation centre (the base point)
+ * rotation  [n_frames][3][3]  row-major
+ * out       [n_frames][s0][s1][s2][3]
+ */
+int mvx_build_coord_volumes(const float* position, const float* center, const float* rotation, int64_t n_frames,
+                            int s0, int s1, int s2, float step0, float step1, float step2, int swap_yz_flip,
+                            float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

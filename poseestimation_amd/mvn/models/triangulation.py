@@ -10,7 +10,6 @@ reference's, so its checkpoints load with strict=True.  Forward-only: the triang
 autograd graph (the reference's algebraic path is not differentiable either, mvn/utils/multiview.py:166).
 """
 import time
-from copy import deepcopy
 
 import numpy as np
 import torch
@@ -158,32 +157,49 @@ class VolumetricTriangulationNet(nn.Module):
         """Coordinate volumes (B, S, S, S, 3), float32, index order [x, y, z]: the cuboid of side
         `cuboid_side` centred on each base point, rotated about the vertical axis by a random angle in
         training mode (one np.random.uniform draw per frame, as the reference) and by 0 otherwise.
-        Reference: mvn/models/triangulation.py:341-385.  Built for the whole batch at once on the device
-        with the reference's float32 operation order."""
+        Reference: mvn/models/triangulation.py:341-385 (a per-frame Python loop of meshgrid, scale, rotate
+        there; one kernel launch here, same float32 operation order).  Returns (volumes, cuboid positions)."""
         S = self.volume_size
         B = base_points_np.shape[0]
         side = float(self.cuboid_side)
         position = base_points_np - side / 2                         # float64, host
-        step = torch.tensor(side / (S - 1), dtype=torch.float32, device=device)
-        pos = torch.from_numpy(position).to(device=device, dtype=torch.float32)         # (B,3)
-        idx = torch.arange(S, dtype=torch.float32, device=device)
-        line = pos.view(B, 3, 1) + (step * idx).view(1, 1, S)        # (B, 3, S): position + step * index
-        coord = torch.empty((B, S, S, S, 3), dtype=torch.float32, device=device)
-        coord[..., 0] = line[:, 0].view(B, S, 1, 1)
-        coord[..., 1] = line[:, 1].view(B, 1, S, 1)
-        coord[..., 2] = line[:, 2].view(B, 1, 1, S)
-        center = torch.from_numpy(base_points_np).to(device=device, dtype=torch.float32)
         axis = [0, 1, 0] if self.kind == "coco" else [0, 0, 1]
         thetas = [np.random.uniform(0.0, 2 * np.pi) if self.training else 0.0 for _ in range(B)]
-        rots = np.stack([volumetric.get_rotation_matrix(axis, th) for th in thetas])
-        rot = torch.from_numpy(rots).type(torch.float).to(device)     # (B,3,3)
-        c = center.view(B, 1, 1, 1, 3)
-        coord = coord - c
-        coord = torch.einsum("bij,bnj->bni", rot, coord.view(B, -1, 3)).view(B, S, S, S, 3)
-        coord = coord + c
-        if self.transfer_cmu_to_human36m:  # different world axes (triangulation.py:380-383)
-            coord = coord.permute(0, 1, 3, 2, 4).flip(2)
-        return coord.contiguous(), position
+        rots = np.stack([volumetric.get_rotation_matrix(axis, th) for th in thetas]) if B else np.zeros((0, 3, 3))
+        # position, centre and rotation travel as one small float32 tensor: [B][3 + 3 + 9]
+        packed = np.concatenate([position, base_points_np, rots.reshape(B, 9)], axis=1).astype(np.float32)
+        params = torch.from_numpy(packed).to(device)
+        pos, center, rot = params[:, 0:3].contiguous(), params[:, 3:6].contiguous(), params[:, 6:15].contiguous()
+        coord = torch.empty((B, S, S, S, 3), dtype=torch.float32, device=device)
+        step = float(np.float32(side / (S - 1)))
+        with torch.cuda.device(device):
+            st = _cabi.load().mvx_build_coord_volumes(
+                _cabi.ptr(pos), _cabi.ptr(center), _cabi.ptr(rot), B, S, S, S, step, step, step,
+                int(bool(self.transfer_cmu_to_human36m)), _cabi.ptr(coord), _cabi.stream(device))
+        _cabi.check(st, "mvx_build_coord_volumes")
+        return coord, position
+
+    @staticmethod
+    def _heatmap_projections(cameras, image_shape, heatmap_shape):
+        """(B, V, 3, 4) float64 projection matrices of the cameras ([V][B] list) after rescaling their
+        intrinsics from the image to the heatmap resolution, without touching the caller's objects.
+        Reference: the deepcopy + Camera.update_after_resize + Camera.projection loop of
+        mvn/models/triangulation.py:309-316, vectorised over all cameras."""
+        n_views, batch_size = len(cameras), len(cameras[0]) if len(cameras) else 0
+        K = np.empty((batch_size, n_views, 3, 3), dtype=np.float64)
+        Rt = np.empty((batch_size, n_views, 3, 4), dtype=np.float64)
+        for v in range(n_views):
+            for b in range(batch_size):
+                cam = cameras[v][b]
+                K[b, v] = cam.K
+                Rt[b, v, :, :3] = cam.R
+                Rt[b, v, :, 3] = np.asarray(cam.t).reshape(3)
+        rx, ry = heatmap_shape[1] / image_shape[1], heatmap_shape[0] / image_shape[0]
+        K[:, :, 0, 0] *= rx    # fx, cx scale with the width ratio; fy, cy with the height ratio
+        K[:, :, 0, 2] *= rx
+        K[:, :, 1, 1] *= ry
+        K[:, :, 1, 2] *= ry
+        return np.matmul(K, Rt)
 
     def forward(self, images, proj_matricies, batch):
         device = images.device
@@ -199,13 +215,7 @@ class VolumetricTriangulationNet(nn.Module):
             vol_confidences = vol_confidences / vol_confidences.sum(dim=1, keepdim=True)
 
         # cameras at heatmap resolution; the projection is built in float64 on the host and cast once
-        new_cameras = deepcopy(batch['cameras'])
-        proj = np.empty((batch_size, n_views, 3, 4), dtype=np.float64)
-        for view_i in range(n_views):
-            for batch_i in range(batch_size):
-                cam = new_cameras[view_i][batch_i]
-                cam.update_after_resize(image_shape, heatmap_shape)
-                proj[batch_i, view_i] = cam.projection
+        proj = self._heatmap_projections(batch['cameras'], image_shape, heatmap_shape)
         proj_matricies = torch.from_numpy(proj).float().to(device)
 
         base_points_np = self._base_points(batch, batch_size)

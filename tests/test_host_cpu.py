@@ -159,3 +159,22 @@ def test_all_gather_keypoints_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
+
+
+def test_heatmap_projections_match_the_camera_loop():
+    """The vectorised camera rescale + projection of the volumetric forward against the per-camera
+    update_after_resize / projection it replaces; the caller's cameras stay untouched."""
+    from copy import deepcopy
+
+    from poseestimation_amd.mvn.models.triangulation import VolumetricTriangulationNet
+    rng = np.random.default_rng(77)
+    K, R, t = synth.make_cameras(rng, 3, 4)
+    cams = [[multiview.Camera(R[v], t[v], K[b, v]) for b in range(3)] for v in range(4)]
+    P = VolumetricTriangulationNet._heatmap_projections(cams, (384, 320), (96, 80))
+    assert P.shape == (3, 4, 3, 4)
+    for v in range(4):
+        for b in range(3):
+            cam = deepcopy(cams[v][b])
+            cam.update_after_resize((384, 320), (96, 80))
+            np.testing.assert_allclose(P[b, v], cam.projection, rtol=1e-15, atol=1e-12)
+            assert np.array_equal(cams[v][b].K, K[b, v])
