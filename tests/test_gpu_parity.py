@@ -80,6 +80,30 @@ def test_soft_argmax_2d_shapes(shape, softmax):
     np.testing.assert_allclose(out.cpu().numpy(), o_out, rtol=2e-5, atol=1e-30)
 
 
+def test_soft_argmax_2d_full_batch_properties():
+    """At the benchmark's size (4096 frames x 4 views x 17 joints = 278 528 maps, 10.3 GB): sampled maps against
+    the oracle, the write-back sums to one per map, coordinates do not depend on the write-back or on where a
+    map sits in the batch, and a constant added to a map leaves its soft-argmax unchanged."""
+    case = synth.device_algebraic_case(1235, 4096, 4, dev())
+    hm = case["heatmaps"].view(-1, 17, 96, 96)
+    coords, out = op.integrate_tensor_2d(hm, True, multiplier=100.0)
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(hm.shape[0], 48, replace=False))
+    sample = hm[torch.from_numpy(pick).to(dev())].cpu().numpy()
+    o_coords, o_out = orc.integrate_tensor_2d(sample * np.float32(100.0), True)
+    assert np.abs(coords[torch.from_numpy(pick).to(dev())].cpu().numpy() - o_coords).max() <= PX_TOL
+    np.testing.assert_allclose(out[torch.from_numpy(pick).to(dev())].cpu().numpy(), o_out, rtol=2e-5, atol=1e-30)
+    sums = out.view(hm.shape[0] * 17, -1).sum(dim=1, dtype=torch.float64)
+    assert float((sums - 1.0).abs().max()) < 1e-5
+    coords_only, _ = op.integrate_tensor_2d(hm, True, multiplier=100.0, return_heatmaps=False)
+    assert torch.equal(coords, coords_only)
+    flipped, _ = op.integrate_tensor_2d(hm.flip(0), True, multiplier=100.0, return_heatmaps=False)
+    assert torch.equal(flipped.flip(0), coords)
+    del out
+    shifted, _ = op.integrate_tensor_2d(hm[:4096] + 0.5, True, multiplier=100.0, return_heatmaps=False)
+    assert float((shifted - coords[:4096]).abs().max()) < 2e-4     # float32 rounding of (x + 0.5) * 100 only
+
+
 def test_soft_argmax_2d_edge_cases():
     empty = torch.empty((0, 17, 96, 96), device=dev())
     coords, out = op.integrate_tensor_2d(empty)
