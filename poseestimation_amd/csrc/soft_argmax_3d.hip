@@ -4,10 +4,10 @@
 // coordinates once into registers and walks the frame's volumes (joints): wave max, exp, and the float64
 // sums (S, Sx, Sy, Sz) of that segment, written as one 40-byte record.  No LDS, no barriers; the coordinate
 // volume is read once per frame instead of once per joint.
-// Pass 2 (finish): per (frame, volume) the records are combined (rescaled to the global max) into the
-// coordinates; when the normalised volumes are wanted the same kernel re-reads the volume and writes
-// exp(t - M) / S.  (Feeding the two passes a few frames at a time so that the second read would hit the
-// Infinity Cache was measured slower than two full-batch launches: the small launches leave CUs idle.)
+// Pass 2 (combine): per (frame, volume) the records are combined (rescaled to the global max) into the
+// coordinates.  Pass 3 (normalize, only when the normalised volumes are wanted): an element-wise stream that
+// re-reads the volumes and writes exp(t - M) / S.  (Feeding the passes a few frames at a time so that the second
+// read would hit the Infinity Cache was measured slower than full-batch launches: small launches leave CUs idle.)
 //
 // Algorithmic bytes per frame: J*N*4 (volumes) + N*12 (coordinates) [+ J*N*4 written] + J*12 out; with the
 // write-back the volumes cross HBM a second time on the read side.
@@ -29,7 +29,10 @@ struct Grid3 {
 template <bool VEC>
 __device__ __forceinline__ float4 load4(const float* __restrict__ p, int64_t i, int64_t n, float fill) {
     if (VEC) {
-        return i < n ? *reinterpret_cast<const float4*>(p + i) : make_float4(fill, fill, fill, fill);
+        if (i >= n) return make_float4(fill, fill, fill, fill);
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const v4 r = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p + i));  // each volume is streamed once per pass
+        return make_float4(r.x, r.y, r.z, r.w);
     } else {
         float4 r;
         r.x = i + 0 < n ? p[i + 0] : fill;
@@ -103,15 +106,25 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_partial(const float* 
 
     const float fill = softmax ? -INFINITY : 0.0f;
     const float* vb = vol + b * J * n_vox;
-    float4 cur[NV], nxt[NV];
+    // two joints are kept in flight behind the one being reduced, so that every wave always has 2 x NV KB of
+    // loads outstanding
+    float4 cur[NV], nxt[NV], nx2[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) cur[k] = load4<VEC>(vb, base + (k * 64 + lane) * 4, n_vox, fill);
+    for (int k = 0; k < NV; ++k) {
+        cur[k] = load4<VEC>(vb, base + (k * 64 + lane) * 4, n_vox, fill);
+        nxt[k] = make_float4(fill, fill, fill, fill);
+        nx2[k] = nxt[k];
+    }
+    if (J > 1) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) nxt[k] = load4<VEC>(vb + n_vox, base + (k * 64 + lane) * 4, n_vox, fill);
+    }
 
     for (int j = 0; j < J; ++j) {
-        if (j + 1 < J) {
-            const float* vn = vb + static_cast<int64_t>(j + 1) * n_vox;
+        if (j + 2 < J) {
+            const float* vn = vb + static_cast<int64_t>(j + 2) * n_vox;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) nxt[k] = load4<VEC>(vn, base + (k * 64 + lane) * 4, n_vox, fill);
+            for (int k = 0; k < NV; ++k) nx2[k] = load4<VEC>(vn, base + (k * 64 + lane) * 4, n_vox, fill);
         }
         float t[NV][4];
 #pragma unroll
@@ -156,27 +169,25 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_partial(const float* 
             rec[4] = sz;
         }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) cur[k] = nxt[k];
+        for (int k = 0; k < NV; ++k) {
+            cur[k] = nxt[k];
+            nxt[k] = nx2[k];
+        }
     }
 }
 
-// Pass 2.  grid.x = n_volumes_total * blocks_per_volume.  Every block combines the volume's records; block 0
-// of a volume stores the coordinates; with WRITE each block normalises its 256*16-voxel slice.
+// Pass 2.  One workgroup per (frame, volume): combines the volume's records into the coordinates and leaves
+// (global max, 1 / sum) for the write-back pass.
 //   mode 0: softmax, out = Sx/S      mode 1: relu, out = Sx (no normalisation)      mode 2: relu, out = Sx/S
-template <bool WRITE, bool VEC>
-__global__ __launch_bounds__(kThreads) void soft_argmax_3d_finish(const float* __restrict__ vol, int64_t n_vox,
-                                                                   int n_seg, int blocks_per_volume, float mult,
-                                                                   int mode, const double* __restrict__ partial,
+__global__ __launch_bounds__(kThreads) void soft_argmax_3d_combine(int n_seg, int mode,
+                                                                   const double* __restrict__ partial,
                                                                    float* __restrict__ out,
-                                                                   float* __restrict__ vol_out) {
+                                                                   float2* __restrict__ stats) {
     __shared__ double red[kThreads / 64][4];
     __shared__ float redm[kThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t volume = blockIdx.x / blocks_per_volume;
-    const int slice = blockIdx.x % blocks_per_volume;
+    const int64_t volume = blockIdx.x;
     const bool softmax = mode == 0;
-    if (!softmax && slice != 0 && !WRITE) return;
-
     const double* rec = partial + volume * n_seg * kRecord;
     float M = 0.0f;
     if (softmax) {
@@ -188,71 +199,67 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_finish(const float* _
         M = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
     }
     double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    if (softmax || slice == 0) {
-        for (int i = tid; i < n_seg; i += kThreads) {
-            const double* r = rec + i * kRecord;
-            // a segment whose values are all -inf has weight exp(-inf) = 0
-            const double wgt = softmax ? exp(r[0] - static_cast<double>(M)) : 1.0;
-            s = fma(r[1], wgt, s);
-            sx = fma(r[2], wgt, sx);
-            sy = fma(r[3], wgt, sy);
-            sz = fma(r[4], wgt, sz);
-        }
-        s = wave_sum(s);
-        sx = wave_sum(sx);
-        sy = wave_sum(sy);
-        sz = wave_sum(sz);
-        if (lane == 0) {
-            red[wave][0] = s;
-            red[wave][1] = sx;
-            red[wave][2] = sy;
-            red[wave][3] = sz;
-        }
-        __syncthreads();
+    for (int i = tid; i < n_seg; i += kThreads) {
+        const double* r = rec + i * kRecord;
+        // a segment whose values are all -inf has weight exp(-inf) = 0
+        const double wgt = softmax ? exp(r[0] - static_cast<double>(M)) : 1.0;
+        s = fma(r[1], wgt, s);
+        sx = fma(r[2], wgt, sx);
+        sy = fma(r[3], wgt, sy);
+        sz = fma(r[4], wgt, sz);
+    }
+    s = wave_sum(s);
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    sz = wave_sum(sz);
+    if (lane == 0) {
+        red[wave][0] = s;
+        red[wave][1] = sx;
+        red[wave][2] = sy;
+        red[wave][3] = sz;
+    }
+    __syncthreads();
+    if (tid == 0) {
         s = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         sx = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
         sy = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
         sz = (red[0][3] + red[1][3]) + (red[2][3] + red[3][3]);
-    }
-    if (slice == 0 && tid == 0) {
         const double d = (mode == 1) ? 1.0 : s;
         out[volume * 3 + 0] = static_cast<float>(sx / d);
         out[volume * 3 + 1] = static_cast<float>(sy / d);
         out[volume * 3 + 2] = static_cast<float>(sz / d);
+        stats[volume] = make_float2(M, softmax ? static_cast<float>(1.0 / s) : 1.0f);
     }
-    if (WRITE) {
-        const float inv = softmax ? static_cast<float>(1.0 / s) : 1.0f;
-        const float* src = vol + volume * n_vox;
-        float* dst = vol_out + volume * n_vox;
-        const int64_t first = static_cast<int64_t>(slice) * (kThreads * 16);
+}
+
+typedef float vec4f __attribute__((ext_vector_type(4)));
+
+// Pass 3 (write-back only): p = exp(t - M) / S (or max(t, 0)) as a plain element-wise stream over all volumes,
+// 4 KB per workgroup, streaming (non-temporal) loads and stores -- the read + write pattern HBM sustains best.
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void soft_argmax_3d_normalize(const float* __restrict__ vol, int64_t n_vox,
+                                                                      int64_t n_total, float mult, int softmax,
+                                                                      const float2* __restrict__ stats,
+                                                                      float* __restrict__ vol_out) {
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * 4;
+    if (i >= n_total) return;
+    if (VEC) {  // n_vox % 4 == 0: the four elements belong to one volume
+        const float2 st = stats[i / n_vox];
+        const vec4f v = __builtin_nontemporal_load(reinterpret_cast<const vec4f*>(vol + i));
+        vec4f p;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t i = first + (k * kThreads + tid) * 4;
-            if (i >= n_vox) continue;
-            float4 t = load4<VEC>(src, i, n_vox, 0.0f);
-            t.x *= mult;
-            t.y *= mult;
-            t.z *= mult;
-            t.w *= mult;
-            float4 p;
-            if (softmax) {
-                p.x = exp_neg(t.x - M) * inv;
-                p.y = exp_neg(t.y - M) * inv;
-                p.z = exp_neg(t.z - M) * inv;
-                p.w = exp_neg(t.w - M) * inv;
-            } else {
-                p.x = fmaxf(t.x, 0.0f);
-                p.y = fmaxf(t.y, 0.0f);
-                p.z = fmaxf(t.z, 0.0f);
-                p.w = fmaxf(t.w, 0.0f);
-            }
-            if (VEC) {
-                *reinterpret_cast<float4*>(dst + i) = p;
-            } else {
-                dst[i] = p.x;
-                if (i + 1 < n_vox) dst[i + 1] = p.y;
-                if (i + 2 < n_vox) dst[i + 2] = p.z;
-                if (i + 3 < n_vox) dst[i + 3] = p.w;
+            const float t = v[k] * mult;
+            p[k] = softmax ? exp_neg(t - st.x) * st.y : fmaxf(t, 0.0f);
+        }
+        __builtin_nontemporal_store(p, reinterpret_cast<vec4f*>(vol_out + i));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < n_total) {
+                const float2 st = stats[(i + k) / n_vox];
+                const float t = vol[i + k] * mult;
+                vol_out[i + k] = softmax ? exp_neg(t - st.x) * st.y : fmaxf(t, 0.0f);
             }
         }
     }
@@ -273,7 +280,7 @@ extern "C" size_t mvx_soft_argmax_3d_workspace_bytes(int64_t n_frames, int n_vol
     if (n_frames <= 0 || n_volumes <= 0 || sx <= 0 || sy <= 0 || sz <= 0) return 0;
     const int64_t n_vox = static_cast<int64_t>(sx) * sy * sz;
     const int64_t n_seg = (n_vox + 255) / 256;  // shortest segment the kernels use
-    return static_cast<size_t>(n_frames) * n_volumes * n_seg * mvx::kRecord * sizeof(double);
+    return static_cast<size_t>(n_frames) * n_volumes * (n_seg * mvx::kRecord * sizeof(double) + sizeof(float2));
 }
 
 extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes,
@@ -298,16 +305,19 @@ extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volu
     const int64_t seg_len = 64 * nv * 4;
     const int64_t n_seg64 = (n_vox + seg_len - 1) / seg_len;
     const int64_t bpf64 = (n_seg64 + 3) / 4;
-    const int64_t bpv64 = volumes_out != nullptr ? (n_vox + kThreads * 16 - 1) / (kThreads * 16) : 1;
-    MVX_REQUIRE(n_seg64 <= (1 << 24) && bpv64 <= (1 << 24), MVX_ERR_UNSUPPORTED,
-                "mvx_soft_argmax_3d: grid of %lld voxels is too large", (long long)n_vox);
-    const int n_seg = static_cast<int>(n_seg64), bpf = static_cast<int>(bpf64), bpv = static_cast<int>(bpv64);
+    MVX_REQUIRE(n_seg64 <= (1 << 24), MVX_ERR_UNSUPPORTED, "mvx_soft_argmax_3d: grid of %lld voxels is too large",
+                (long long)n_vox);
+    const int n_seg = static_cast<int>(n_seg64), bpf = static_cast<int>(bpf64);
     const int mode = softmax ? 0 : (coords_volume != nullptr ? 1 : 2);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partial = static_cast<double*>(workspace);
 
-    MVX_REQUIRE(n_frames * bpf <= 0x7fffffffLL && n_frames * n_volumes * bpv <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED,
-                "mvx_soft_argmax_3d: batch exceeds the launch limits");
+    const int64_t n_total = n_frames * n_volumes * n_vox;
+    const int64_t norm_blocks = (n_total + kThreads * 4 - 1) / (kThreads * 4);
+    MVX_REQUIRE(n_frames * bpf <= 0x7fffffffLL && n_frames * n_volumes <= 0x7fffffffLL && norm_blocks <= 0x7fffffffLL,
+                MVX_ERR_UNSUPPORTED, "mvx_soft_argmax_3d: batch exceeds the launch limits");
+    // the (max, 1/sum) pairs of pass 2 live behind the records (sized for the shortest segments)
+    float2* stats = reinterpret_cast<float2*>(partial + n_frames * n_volumes * ((n_vox + 255) / 256) * kRecord);
 
     const dim3 grid1(static_cast<unsigned>(n_frames * bpf)), block(kThreads);
 #define MVX_LAUNCH_PARTIAL(NV, VEC)                                                                              \
@@ -320,14 +330,18 @@ extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volu
 #undef MVX_LAUNCH_PARTIAL
     MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (partial)");
 
-    const dim3 grid2(static_cast<unsigned>(n_frames * n_volumes * bpv));
-#define MVX_LAUNCH_FINISH(WRITE, VEC)                                                                             \
-    hipLaunchKernelGGL((soft_argmax_3d_finish<WRITE, VEC>), grid2, block, 0, st, volumes, n_vox, n_seg, bpv, \
-                       multiplier, mode, partial, out, volumes_out)
-    if (volumes_out != nullptr && vec) MVX_LAUNCH_FINISH(true, true);
-    else if (volumes_out != nullptr) MVX_LAUNCH_FINISH(true, false);
-    else MVX_LAUNCH_FINISH(false, false);
-#undef MVX_LAUNCH_FINISH
-    MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (finish)");
+    hipLaunchKernelGGL(soft_argmax_3d_combine, dim3(static_cast<unsigned>(n_frames * n_volumes)), block, 0, st, n_seg,
+                       mode, partial, out, stats);
+    MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (combine)");
+    if (volumes_out != nullptr) {
+        const dim3 grid3(static_cast<unsigned>(norm_blocks));
+        if (vec)
+            hipLaunchKernelGGL(soft_argmax_3d_normalize<true>, grid3, block, 0, st, volumes, n_vox, n_total, multiplier,
+                               softmax, stats, volumes_out);
+        else
+            hipLaunchKernelGGL(soft_argmax_3d_normalize<false>, grid3, block, 0, st, volumes, n_vox, n_total,
+                               multiplier, softmax, stats, volumes_out);
+        MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (normalize)");
+    }
     return MVX_OK;
 }

@@ -84,13 +84,10 @@ def k3(rounds):
 def k4(rounds):
     case = synth.device_volumetric_case(5, 64, 4, dev)
     v, c = case["volumes"], case["coord_volumes"]
-    for nv in (1, 4):
-        os.environ["MVX_SAM3D_NV"] = str(nv)
-        print("-- NV", nv)
-        time_variants(lambda: op.integrate_tensor_3d_with_coordinates(v, c), "MVX_SAM3D_FINISH_LDS_KB", [0, 16, 24, 36, 48, 72], rounds, inner=2)
-    os.environ.pop("MVX_SAM3D_NV", None)
+    print("-- with write-back")
+    time_variants(lambda: op.integrate_tensor_3d_with_coordinates(v, c), "MVX_UNUSED", [0], rounds, inner=2)
     print("-- coords only")
-    time_variants(lambda: (op.integrate_tensor_3d_with_coordinates(v, c, return_volumes=False)[0],), "MVX_SAM3D_NV", [1, 4], rounds, inner=2)
+    time_variants(lambda: (op.integrate_tensor_3d_with_coordinates(v, c, return_volumes=False)[0],), "MVX_UNUSED", [0], rounds, inner=2)
 
 
 if __name__ == "__main__":
