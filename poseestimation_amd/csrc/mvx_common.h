@@ -65,6 +65,26 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<0x140>(v));
     return fmaxf(fmaxf(read_lane(v, 0), read_lane(v, 16)), fmaxf(read_lane(v, 32), read_lane(v, 48)));
 }
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_movi<0xB1>(v));
+    v = min(v, dpp_movi<0x4E>(v));
+    v = min(v, dpp_movi<0x141>(v));
+    v = min(v, dpp_movi<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, dpp_movi<0xB1>(v));
+    v = max(v, dpp_movi<0x4E>(v));
+    v = max(v, dpp_movi<0x141>(v));
+    v = max(v, dpp_movi<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_mov<0xB1>(v);
     v += dpp_mov<0x4E>(v);

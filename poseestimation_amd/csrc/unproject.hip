@@ -138,17 +138,45 @@ struct Aggregator {
     }
 };
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// The 2 x 2 taps of four channels.  `img` is uniform over the wave, so the four loads share two scalar bases
+// (the two rows) and one 32-bit lane offset (host code keeps an image below 4 GB).
+struct Taps4 {
+    float4 f00, f01, f10, f11;
+};
+__device__ __forceinline__ Taps4 load_taps(const float* __restrict__ img, unsigned pixel, int W, int Cp, int q) {
+    const char* row0 = reinterpret_cast<const char*>(img);
+    const char* row1 = row0 + static_cast<size_t>(W) * Cp * sizeof(float);
+    const unsigned off = (pixel * static_cast<unsigned>(Cp) + static_cast<unsigned>(q) * 4u) * 4u;
+    Taps4 t;
+    t.f00 = *reinterpret_cast<const float4*>(row0 + off);
+    t.f01 = *reinterpret_cast<const float4*>(row0 + off + Cp * sizeof(float));
+    t.f10 = *reinterpret_cast<const float4*>(row1 + off);
+    t.f11 = *reinterpret_cast<const float4*>(row1 + off + Cp * sizeof(float));
+    return t;
+}
+// fma(f11, w11, fma(f10, w10, fma(f01, w01, f00 * w00))) per channel, two channels per packed instruction
+// (each half rounds exactly as the scalar instruction does).
+__device__ __forceinline__ void interpolate(const Taps4& t, const float4& w, float (&val)[4]) {
+    const float2v w00 = {w.x, w.x}, w01 = {w.y, w.y}, w10 = {w.z, w.z}, w11 = {w.w, w.w};
+    const float2v lo = __builtin_elementwise_fma(
+        float2v{t.f11.x, t.f11.y}, w11,
+        __builtin_elementwise_fma(float2v{t.f10.x, t.f10.y}, w10,
+                                  __builtin_elementwise_fma(float2v{t.f01.x, t.f01.y}, w01, float2v{t.f00.x, t.f00.y} * w00)));
+    const float2v hi = __builtin_elementwise_fma(
+        float2v{t.f11.z, t.f11.w}, w11,
+        __builtin_elementwise_fma(float2v{t.f10.z, t.f10.w}, w10,
+                                  __builtin_elementwise_fma(float2v{t.f01.z, t.f01.w}, w01, float2v{t.f00.z, t.f00.w} * w00)));
+    val[0] = lo.x;
+    val[1] = lo.y;
+    val[2] = hi.x;
+    val[3] = hi.y;
+}
 __device__ __forceinline__ void sample4(const float* __restrict__ img, const Tap& t, int W, int Cp, int q,
                                         float (&val)[4]) {
-    const float* p = img + static_cast<size_t>(t.pixel) * Cp + q * 4;
-    const float4 f00 = *reinterpret_cast<const float4*>(p);
-    const float4 f01 = *reinterpret_cast<const float4*>(p + Cp);
-    const float4 f10 = *reinterpret_cast<const float4*>(p + static_cast<size_t>(W) * Cp);
-    const float4 f11 = *reinterpret_cast<const float4*>(p + static_cast<size_t>(W) * Cp + Cp);
-    val[0] = fmaf(f11.x, t.w11, fmaf(f10.x, t.w10, fmaf(f01.x, t.w01, f00.x * t.w00)));
-    val[1] = fmaf(f11.y, t.w11, fmaf(f10.y, t.w10, fmaf(f01.y, t.w01, f00.y * t.w00)));
-    val[2] = fmaf(f11.z, t.w11, fmaf(f10.z, t.w10, fmaf(f01.z, t.w01, f00.z * t.w00)));
-    val[3] = fmaf(f11.w, t.w11, fmaf(f10.w, t.w10, fmaf(f01.w, t.w01, f00.w * t.w00)));
+    const Taps4 f = load_taps(img, t.pixel, W, Cp, q);
+    interpolate(f, make_float4(t.w00, t.w01, t.w10, t.w11), val);
 }
 
 // [n][C][HW] -> [n][HW][Cp], Cp = C rounded up to 4 (pad = 0).  64-pixel x 32-channel tiles through LDS.
@@ -277,18 +305,18 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
         }
         for (int step = 0; step < kTile / 32; ++step) {
             const int t = step * 32 + (tid >> 3);
-            float val[4][4];
+            // all sixteen loads of the step are issued before the first value is used
+            float4 w4[4];
+            Taps4 f[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float4 w4 = wts[v * kTile + t];
-                Tap tap;
-                tap.w00 = w4.x;
-                tap.w01 = w4.y;
-                tap.w10 = w4.z;
-                tap.w11 = w4.w;
-                tap.pixel = pix[v * kTile + t];
-                sample4(fb + v * img_stride, tap, W, C, q, val[v]);
+                w4[v] = wts[v * kTile + t];
+                f[v] = load_taps(fb + v * img_stride, pix[v * kTile + t], W, C, q);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            float val[4][4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) interpolate(f[v], w4[v], val[v]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float r;
@@ -381,8 +409,8 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
                 MVX_ERR_WORKSPACE, "mvx_unproject: workspace of %zu bytes is too small", workspace_bytes);
     MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: workspace must be 16-byte aligned");
     const int C = n_channels, Cp = (C + 3) / 4 * 4, V = n_views, HW = h * w;
-    MVX_REQUIRE(static_cast<int64_t>(h) * w * Cp < (1LL << 31), MVX_ERR_UNSUPPORTED,
-                "mvx_unproject: one feature map exceeds 2^31 elements");
+    MVX_REQUIRE(static_cast<int64_t>(h) * w * Cp < (1LL << 30), MVX_ERR_UNSUPPORTED,
+                "mvx_unproject: one feature map exceeds 2^30 elements (4 GB)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* feat_cl = static_cast<float*>(workspace);
     const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
