@@ -155,6 +155,65 @@ int mvx_build_coord_volumes(const float* position, const float* center, const fl
                             int s0, int s1, int s2, float step0, float step1, float step2, int swap_yz_flip,
                             float* out, void* stream);
 
+/*
+ * Integer keypoints at the heatmap maxima, scaled to image pixels: replaces the arg-max and the upscale of
+ * RANSACTriangulationNet.forward, mvn/models/triangulation.py:48-56.  Per map the flat index of the maximum
+ * (torch.max ordering: NaN first, then the largest value; the lowest index among equals) is split into
+ * x = index % w, y = index / w, and each is multiplied in float32 by its scale and truncated toward zero.
+ * heatmaps   [n_maps][h][w]
+ * keypoints  [n_maps][2] int64 (x, y)
+ */
+int mvx_heatmap_argmax(const float* heatmaps, int64_t n_maps, int h, int w, float scale_x, float scale_y,
+                       int64_t* keypoints, void* stream);
+
+/*
+ * RANSAC triangulation of every (frame, joint): replaces RANSACTriangulationNet.triangulate_ransac and the
+ * loop that calls it, mvn/models/triangulation.py:67-73, 83-148, with mvn/utils/multiview.py:115-140 (DLT) and
+ * :201-208 (reprojection error, HALF the pixel distance) inside.  For each of the n_iters view pairs: DLT from
+ * the two views, inliers = the pair plus every view whose reprojection error is below epsilon; the first largest
+ * inlier set wins; DLT over it; with direct_optimization != 0 the point is then moved to the minimiser of
+ * 1/2 sum huber(error^2) over the inlier views (what scipy's least_squares(loss='huber') approaches from the
+ * same start).  All arithmetic in float64.  The pairs come from the caller: the reference draws them with
+ * Python's random.sample, and results match it only for the same draws.
+ * proj          [n_frames][n_views][3][4]
+ * points        [n_frames][n_views][n_joints][2]  float64 keypoints
+ * view_pairs    [n_frames][n_joints][n_iters][2]  view indices; a pair with an index >= n_views is skipped
+ * out           [n_frames][n_joints][3]           float64
+ * inlier_masks  [n_frames][n_joints]              bit v set = view v is an inlier (n_views <= 32)
+ */
+int mvx_triangulate_ransac(const float* proj, const double* points, const uint8_t* view_pairs, int64_t n_frames,
+                           int n_views, int n_joints, int n_iters, double epsilon, int direct_optimization,
+                           double* out, uint32_t* inlier_masks, void* stream);
+
+/*
+ * Savitzky-Golay smoothing of time series: replaces SAVGOLFilter.__call__, savgol_filer.py:32-70
+ * (scipy.signal.savgol_filter(x, window, polyorder, axis=0), default mode 'interp', applied per coordinate).
+ * hat is the window x window hat matrix A pinv(A) of the polynomial fit (A = Vandermonde matrix of the window
+ * positions, polyorder + 1 columns), float64, device memory: interior samples use its middle row on the window
+ * centred on them, the first and last window/2 samples use rows 0.. / ..window-1 on the first / last window.
+ * window must be odd, or equal to n_steps (the reference cuts the window to a short sequence).
+ * x, out  [n_steps][n_series]   (a [T][K][C] pose tensor is n_series = K*C)
+ */
+int mvx_savgol_filter(const float* x, int64_t n_steps, int64_t n_series, const double* hat, int window, float* out,
+                      void* stream);
+
+/*
+ * Joint order and axis convention of the real-time pipelines' wire format: replaces the loop of
+ * real_pipeline_trt.py:371-396.  out[f][j] = scale * (-x, z, -y) of points[f][joint_order[j]], float32.
+ * points, out  [n_frames][n_joints][3];  joint_order  [n_joints] int32, device memory
+ */
+int mvx_unity_points(const float* points, const int32_t* joint_order, int64_t n_frames, int n_joints, float scale,
+                     float* out, void* stream);
+
+/*
+ * The per-frame tail of the real-time pipelines in one launch: replaces real_pipeline_trt.py:360-396 for a
+ * full window.  frames holds the last n_steps poses; they are smoothed as by mvx_savgol_filter, and out[0] is
+ * the mean of the last two smoothed poses, out[1] the last smoothed pose, both mapped as by mvx_unity_points.
+ * frames  [n_steps][n_joints][3];  out  [2][n_joints][3]
+ */
+int mvx_realtime_tail(const float* frames, int n_steps, int n_joints, const double* hat, int window,
+                      const int32_t* joint_order, float scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,9 +269,95 @@ def time_port_vs_reference():
             "max_abs_diff_kp3d_mm": float((a - b[0]).abs().max()), "max_abs_diff_kp2d_px": float((kpa - b[1]).abs().max())}
 
 
+def gen_ransac():
+    """RANSACTriangulationNet: arg-max keypoints, triangulate_ransac per point (both settings of
+    direct_optimization) and the whole forward, with Python's random seeded before each."""
+    import random
+    import warnings
+    warnings.simplefilter("ignore", DeprecationWarning)      # random.sample on a set (triangulation.py:97)
+    case = gc.ransac_inputs()
+    hm, proj, kp = case["heatmaps"], case["proj"], case["keypoints"]
+    B, V, J, h, w = hm.shape
+    net = ref_tri.RANSACTriangulationNet.__new__(ref_tri.RANSACTriangulationNet)
+    torch.nn.Module.__init__(net)
+    out = {"input_sha": gc.sha(hm, proj, kp)}
+    for direct in (False, True):
+        random.seed(gc.RANSAC_RANDOM_SEED)
+        pts = np.zeros((B, J, 3))
+        masks = np.zeros((B, J), dtype=np.int64)
+        for b in range(B):
+            for j in range(J):
+                X, inl = net.triangulate_ransac(proj[b], kp[b, :, j], direct_optimization=direct)
+                pts[b, j] = X
+                masks[b, j] = sum(1 << int(v) for v in inl)
+        tag = "refined" if direct else "dlt"
+        out["points_" + tag] = pts
+        out["masks_" + tag] = masks
+    # forward with a stub backbone (heatmaps as given); 384-px images
+    net.backbone = _StubBackbone(t(hm).view(B * V, J, h, w), None, None, None)
+    for direct in (False, True):
+        net.direct_optimization = direct
+        random.seed(gc.RANSAC_RANDOM_SEED + 1)
+        with torch.no_grad():
+            kp3d, kp2d, hm_out, conf = net(torch.zeros(B, V, 3, 384, 384), t(proj), None)
+        tag = "refined" if direct else "dlt"
+        out["forward_kp3d_" + tag] = kp3d.numpy()
+        out["forward_kp2d"] = kp2d.numpy()
+        out["forward_conf"] = conf.numpy()
+    save("ransac", **out)
+
+
+def gen_datasets():
+    from mvn.datasets import utils as ref_data
+    items = gc.dataset_items(multiview.Camera)
+    out = {}
+    for rand in (True, False):
+        tag = "rand" if rand else "all"
+        np.random.seed(5)
+        batch = ref_data.make_collate_fn(rand, 3, 6)(items + [None])
+        images, kp, validity, proj = ref_data.prepare_batch(batch, "cpu", None)
+        out["images_sha_" + tag] = gc.sha(images.numpy())
+        out["detections_" + tag] = batch["detections"]
+        out["kp_" + tag] = kp.numpy()
+        out["validity_" + tag] = validity.numpy()
+        out["proj_" + tag] = proj.numpy()
+        np.random.seed(6)
+        batch = ref_data.make_collate_fn_test(rand, 3, 6)(items)
+        images, proj = ref_data.prepare_batch_test(batch, "cpu", None)
+        out["test_images_sha_" + tag] = gc.sha(images.numpy())
+        out["test_proj_" + tag] = proj.numpy()
+    sample = {"inps": [torch.from_numpy(im.transpose(2, 0, 1).copy()).float() for im in items[0]["images"][:4]],
+              "cameras": items[0]["cameras"][:4]}
+    images, proj = ref_data.prepare_batch_video(sample, 4, "cpu")
+    out["video_images_sha"] = gc.sha(images.numpy())
+    out["video_proj"] = proj.numpy()
+    save("datasets", **out)
+
+
+def gen_savgol():
+    sys.path.insert(0, REFERENCE)
+    from savgol_filer import SAVGOLFilter   # the reference's module (its file name)
+    out = {}
+    for i, (T, window) in enumerate(gc.SAVGOL_CASES):
+        x = gc.savgol_input(i)
+        y, _ = SAVGOLFilter(window)(x)
+        assert y.dtype == np.float32
+        out["y%d" % i] = y
+        yt, _ = SAVGOLFilter(window)(torch.from_numpy(x))
+        assert torch.equal(yt, torch.from_numpy(y))
+    save("savgol", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
+    if len(sys.argv) > 1:                     # regenerate selected fixtures only: ransac, datasets, savgol
+        for name in sys.argv[1:]:
+            {"ransac": gen_ransac, "datasets": gen_datasets, "savgol": gen_savgol}[name]()
+        sys.exit(0)
+    gen_ransac()
+    gen_datasets()
+    gen_savgol()
     gen_algebraic()
     gen_volumetric_small()
     vol_timing = gen_volumetric_full()

@@ -78,3 +78,49 @@ def full_volumetric_inputs():
 
 
 UNPROJECT_METHODS = ("sum", "max", "softmax", "conf", "conf_norm")
+
+
+# ---- RANSAC triangulation ----------------------------------------------------------------------------------
+RANSAC_SEED = 1250
+RANSAC_RANDOM_SEED = 20240          # random.seed() before each reference call that draws view pairs
+
+
+def ransac_inputs():
+    """Algebraic-style heatmaps (B=3, V=4) and projections; `keypoints` are the arg-max keypoints with view 1
+    of every third joint pushed 40-120 px away, so that the consensus search has outliers to reject."""
+    case = synth.algebraic_case(RANSAC_SEED, 3, 4)
+    hm = case["heatmaps"]
+    B, V, J, h, w = hm.shape
+    flat = np.argmax(hm.reshape(B, V, J, -1), axis=-1)
+    kp = np.stack([(flat % w) * 4, (flat // w) * 4], axis=-1).astype(np.int64)
+    rng = np.random.default_rng(RANSAC_SEED + 1)
+    kp[:, 1, ::3] += rng.integers(40, 120, size=kp[:, 1, ::3].shape)
+    return {"heatmaps": hm, "proj": case["proj"], "keypoints": kp}
+
+
+# ---- data-loader glue ----------------------------------------------------------------------------------------
+def dataset_items(camera_cls, n_items=3, n_views=12, seed=1260):
+    """Items as the reference's datasets yield them: per-view images, detections and cameras, 3-D ground truth."""
+    rng = np.random.default_rng(seed)
+    items = []
+    for i in range(n_items):
+        cams = []
+        for _ in range(n_views):
+            K = np.array([[1145.0, 0, 512.0], [0, 1143.0, 515.0], [0, 0, 1.0]]) + rng.uniform(0, 1, (3, 3))
+            cams.append(camera_cls(np.linalg.qr(rng.standard_normal((3, 3)))[0], rng.uniform(-3000, 3000, (3, 1)), K))
+        items.append({"images": [rng.uniform(-2, 2, (8, 10, 3)) for _ in range(n_views)],
+                      "detections": [rng.uniform(0, 100, 5) for _ in range(n_views)],
+                      "cameras": cams, "keypoints_3d": rng.uniform(-1000, 1000, (17, 4)), "indexes": i,
+                      "actname": "act%d" % i, "pred_keypoints_3d": rng.uniform(-1, 1, (17, 3))})
+    return items
+
+
+# ---- temporal filter -------------------------------------------------------------------------------------------
+SAVGOL_CASES = ((8, 8), (5, 8), (4, 8), (2, 8), (3, 8), (64, 9), (300, 31), (9, 9), (40, 6))   # (T, window_size)
+
+
+def savgol_input(i):
+    T, _ = SAVGOL_CASES[i]
+    rng = np.random.default_rng(1270 + i)
+    walk = np.cumsum(rng.standard_normal((T, 17, 3)) * 15.0, axis=0) + rng.uniform(-800, 800, (1, 17, 3))
+    return walk.astype(np.float32)

@@ -338,3 +338,182 @@ def build_coord_volume(base_point, cuboid_side, volume_size, theta=0.0, axis=(0,
     rot = get_rotation_matrix(axis, theta)
     g = ((g - base).reshape(-1, 3) @ rot.T).reshape(S, S, S, 3) + base
     return g
+
+
+# ----------------------------------------------------------------------------
+# RANSAC triangulation                 reference: mvn/models/triangulation.py:19-148
+# ----------------------------------------------------------------------------
+def heatmap_argmax_keypoints(heatmaps, image_shape):
+    """heatmaps (B, V, J, h, w) -> (B, V, J, 2) int64 [x, y] in image pixels.  The flat arg-max (first maximal
+    entry; a NaN counts as maximal, as in torch.max) is split into column and row, and each is multiplied by
+    image/heatmap size in float32 and truncated: an int64 tensor times a Python float is a float32 tensor in
+    torch, and the reference assigns it into an int64 tensor.  Reference: triangulation.py:48-56."""
+    B, V, J, h, w = heatmaps.shape
+    flat = np.argmax(heatmaps.reshape(B, V, J, h * w), axis=-1)
+    x, y = flat % w, flat // w
+    sx, sy = np.float32(image_shape[1] / w), np.float32(image_shape[0] / h)
+    out = np.empty((B, V, J, 2), dtype=np.int64)
+    out[..., 0] = np.trunc(x.astype(np.float32) * sx).astype(np.int64)
+    out[..., 1] = np.trunc(y.astype(np.float32) * sy).astype(np.int64)
+    return out
+
+
+def dlt_numpy(proj_matricies, points):
+    """Unweighted DLT in float64 with numpy's SVD.  Reference: mvn/utils/multiview.py:115-140."""
+    n = len(proj_matricies)
+    A = np.zeros((2 * n, 4))
+    for v in range(n):
+        P = np.asarray(proj_matricies[v], dtype=np.float64)
+        A[2 * v] = np.float64(points[v][0]) * P[2] - P[0]
+        A[2 * v + 1] = np.float64(points[v][1]) * P[2] - P[1]
+    vh = np.linalg.svd(A, full_matrices=False)[2]
+    return vh[3, :3] / vh[3, 3]
+
+
+def reprojection_errors(point_3d, points, proj_matricies):
+    """HALF the pixel distance between each keypoint and the projection of `point_3d`, per view.
+    Reference: mvn/utils/multiview.py:201-208 (note the 1/2 at :205)."""
+    Xh = np.append(np.asarray(point_3d, dtype=np.float64), 1.0)
+    errs = np.empty(len(points))
+    for v in range(len(points)):
+        q = np.asarray(proj_matricies[v], dtype=np.float64) @ Xh
+        errs[v] = 0.5 * np.sqrt(np.sum((np.asarray(points[v], dtype=np.float64) - q[:2] / q[2]) ** 2))
+    return errs
+
+
+def triangulate_ransac(proj_matricies, points, view_pairs, reprojection_error_epsilon=15, direct_optimization=True):
+    """One point.  `view_pairs` (n_iters, 2) are the sorted view pairs the reference would have drawn with
+    random.sample (triangulation.py:97).  Returns (point (3,) float64, sorted inlier indices).
+    Reference: triangulation.py:83-148; the refinement is scipy.optimize.least_squares(loss='huber',
+    method='trf') on the vector of reprojection errors, as at :133-142."""
+    proj_matricies = np.asarray(proj_matricies)
+    points = np.asarray(points)
+    n_views = len(points)
+    inliers = set()
+    for a, b in view_pairs:
+        sampled = [int(a), int(b)]
+        X = dlt_numpy(proj_matricies[sampled], points[sampled])
+        errs = reprojection_errors(X, points, proj_matricies)
+        new = set(sampled) | {v for v in range(n_views) if errs[v] < reprojection_error_epsilon}
+        if len(new) > len(inliers):
+            inliers = new
+    if not inliers:
+        inliers = set(range(n_views))
+    idx = np.array(sorted(inliers))
+    X = dlt_numpy(proj_matricies[idx], points[idx])
+    if direct_optimization:
+        from scipy.optimize import least_squares
+        res = least_squares(lambda x: reprojection_errors(x, points[idx], proj_matricies[idx]), np.array(X),
+                            loss="huber", method="trf")
+        X = res.x
+    return X, idx
+
+
+def huber_minimiser(start, points, proj_matricies):
+    """The point the refinement at triangulation.py:140 is heading for: the same least_squares problem run to
+    machine-precision tolerances instead of scipy's default ftol = xtol = gtol = 1e-8 (at which it stops up to
+    1.3e-2 mm short on the fixtures here)."""
+    from scipy.optimize import least_squares
+    res = least_squares(lambda x: reprojection_errors(x, points, proj_matricies), np.array(start, dtype=np.float64),
+                        loss="huber", method="trf", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=5000)
+    return res.x
+
+
+def huber_cost(point_3d, points, proj_matricies):
+    """The objective least_squares minimises at triangulation.py:140: 1/2 sum rho(r^2), rho Huber with unit scale."""
+    s = reprojection_errors(point_3d, points, proj_matricies) ** 2
+    return 0.5 * np.sum(np.where(s <= 1.0, s, 2.0 * np.sqrt(s) - 1.0))
+
+
+def ransac_batch(proj_matricies, keypoints_2d, view_pairs, reprojection_error_epsilon=15, direct_optimization=True):
+    """proj (B, V, 3, 4), keypoints_2d (B, V, J, 2), view_pairs (B*J, n_iters, 2) -> ((B, J, 3) float64,
+    (B, J) inlier bit masks).  Reference loop: triangulation.py:67-73."""
+    B, V, J = keypoints_2d.shape[:3]
+    out = np.zeros((B, J, 3))
+    masks = np.zeros((B, J), dtype=np.int64)
+    for b in range(B):
+        for j in range(J):
+            X, idx = triangulate_ransac(proj_matricies[b], keypoints_2d[b, :, j], view_pairs[b * J + j],
+                                        reprojection_error_epsilon, direct_optimization)
+            out[b, j] = X
+            masks[b, j] = sum(1 << int(v) for v in idx)
+    return out, masks
+
+
+# ----------------------------------------------------------------------------
+# temporal Savitzky-Golay filter       reference: savgol_filer.py:7-70 (scipy.signal.savgol_filter inside)
+# ----------------------------------------------------------------------------
+def savgol_window(window_size, n_steps, polyorder=2):
+    """The window and polynomial order the reference ends up using (savgol_filer.py:33-45): an even window
+    loses one sample, a window longer than the sequence is cut to it, the order drops below the window."""
+    window = window_size - 1 if window_size % 2 == 0 else window_size
+    window = min(window, n_steps)
+    order = window - 1 if window <= polyorder else polyorder
+    assert order > 0 and window > order
+    return window, order
+
+
+def savgol_filter(x, window, order):
+    """scipy.signal.savgol_filter(x, window, order, axis=0) with its default mode='interp', restated with
+    explicit least-squares fits, float64: away from the ends each output is the value at the window centre of
+    the polynomial fitted to the window around it; the first and last window//2 outputs are read off the
+    polynomial fitted to the first and last `window` samples.  x (T, ...)."""
+    x = np.asarray(x, dtype=np.float64)
+    T = x.shape[0]
+    flat = x.reshape(T, -1)
+    half = window // 2
+    t = np.arange(window, dtype=np.float64)
+    vander = np.vander(t, order + 1)                      # columns t^order ... t^0
+    out = np.empty_like(flat)
+    for c in range(half, T - half):
+        if window % 2 == 0:
+            break                                          # an even window equals T here: ends cover everything
+        coef = np.linalg.lstsq(vander, flat[c - half:c + half + 1], rcond=None)[0]
+        out[c] = np.polyval(coef, float(half))
+    head = np.linalg.lstsq(vander, flat[:window], rcond=None)[0]
+    tail = np.linalg.lstsq(vander, flat[T - window:], rcond=None)[0]
+    for i in range(half):
+        out[i] = np.polyval(head, float(i))
+        out[T - half + i] = np.polyval(tail, float(window - half + i))
+    return out.reshape(x.shape)
+
+
+def savgol_smooth(x, window_size):
+    """SAVGOLFilter(window_size)(x) for x (T, K, C): every coordinate series filtered along T.  Returns float64;
+    the reference stores into an array of x's dtype (savgol_filer.py:54-60)."""
+    window, order = savgol_window(window_size, x.shape[0])
+    return savgol_filter(x, window, order)
+
+
+# ----------------------------------------------------------------------------
+# wire format of the real-time pipelines      reference: real_pipeline_trt.py:357-399
+# (inline script code that cannot be imported: this restatement is NOT pinned by reference outputs)
+# ----------------------------------------------------------------------------
+UNITY_JOINTS = ('Hip', 'RightHip', 'RightKnee', 'RightAnkle', 'LeftHip', 'LeftKnee', 'LeftAnkle', 'Spine', 'Thorax',
+                'Neck', 'Head', 'LeftShoulder', 'LeftElbow', 'LeftWrist', 'RightShoulder', 'RightElbow', 'RightWrist')
+UNITY_ORDER = (6, 2, 1, 0, 3, 4, 5, 7, 8, 16, 9, 13, 14, 15, 12, 11, 10)
+
+
+def unity_points(points, order=UNITY_ORDER):
+    """(J, 3) float32 -> joints reordered and axes mapped (x, y, z) -> (-x, z, -y).  real_pipeline_trt.py:371-384."""
+    p = np.asarray(points, dtype=np.float32)[list(order)]
+    return np.stack([-p[:, 0], p[:, 2], -p[:, 1]], axis=1)
+
+
+def unity_scale(first_frame_points, unity_len=0.43):
+    """unity_len over the length of the bone between reordered joints 2 and 3 of the first frame (:386-392)."""
+    p = unity_points(first_frame_points)
+    return unity_len / np.linalg.norm(p[2] - p[3])
+
+
+def unity_message(points, scale, names=UNITY_JOINTS):
+    """{joint name: [x, y, z]} of Python floats (:393-396)."""
+    p = unity_points(points)
+    return {names[j]: [float(p[j][0] * scale), float(p[j][1] * scale), float(p[j][2] * scale)] for j in range(len(p))}
+
+
+def realtime_window_frames(window):
+    """window (8, J, 3) float32 of the last frames -> the two frames the pipeline sends: the mean of the last two
+    filtered frames and the last filtered frame (:360-367, filter window 8 -> 7)."""
+    sm = savgol_smooth(np.asarray(window, dtype=np.float32).transpose(0, 2, 1), 8).astype(np.float32).transpose(0, 2, 1)
+    return [(sm[-1] + sm[-2]) / 2, sm[-1]]

@@ -8,82 +8,13 @@
 // off-diagonal entry is below 1e-18 of the geometric mean of its diagonal neighbours).
 // HBM traffic per point: 48*V (P, shared by the joints of a frame) + 8*V (points) + 4*V (conf) + 12 bytes out.
 #include "mvx_common.h"
+#include "sym4_eigen.h"
 
 namespace mvx {
 
 namespace {
 
 constexpr int kThreads = 128;
-constexpr int kMaxSweeps = 16;
-
-// 1/x and 1/sqrt(x) to float64 accuracy from the hardware estimates (v_rcp_f64 / v_rsq_f64, about 2^-26 relative
-// error, refined by two Newton steps each): a much shorter dependent chain than the IEEE division and square
-// root routines, which matters because one lane walks 6 rotations x several sweeps serially.
-__device__ __forceinline__ double rcp_refined(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(y, fma(-x, y, 1.0), y);
-    y = fma(y, fma(-x, y, 1.0), y);
-    return y;
-}
-__device__ __forceinline__ double rsqrt_refined(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * fma(-0.5 * x, y * y, 1.5);
-    y = y * fma(-0.5 * x, y * y, 1.5);
-    return y;
-}
-
-// One Jacobi rotation annihilating a[P][Q] (P < Q); a is kept full and symmetric, v accumulates the
-// rotations (columns of v are the eigenvectors).  t = tan(angle) is the smaller root of t^2 + 2 t theta - 1 = 0,
-// theta = (a_qq - a_pp) / (2 a_pq); for |theta| beyond 1e100 the square would overflow and t = 1 / (2 theta).
-template <int P, int Q>
-__device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][4]) {
-    const double apq = a[P][Q];
-    if (apq == 0.0) return;
-    const double theta = (a[Q][Q] - a[P][P]) * 0.5 * rcp_refined(apq);
-    const double ath = fabs(theta);
-    double t;
-    if (ath < 1e100) {
-        const double x = fma(theta, theta, 1.0);
-        t = rcp_refined(ath + x * rsqrt_refined(x));
-    } else {
-        t = 0.5 * rcp_refined(ath);  // also the limit for theta = inf (t = 0); NaN falls through to the check below
-    }
-    t = theta >= 0.0 ? t : -t;
-    if (!(t == t)) return;
-    const double c = rsqrt_refined(fma(t, t, 1.0));
-    const double s = t * c;
-    a[P][P] = fma(-t, apq, a[P][P]);
-    a[Q][Q] = fma(t, apq, a[Q][Q]);
-    a[P][Q] = 0.0;
-    a[Q][P] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k != P && k != Q) {
-            const double akp = a[k][P], akq = a[k][Q];
-            const double np_ = c * akp - s * akq;
-            const double nq_ = s * akp + c * akq;
-            a[k][P] = np_;
-            a[P][k] = np_;
-            a[k][Q] = nq_;
-            a[Q][k] = nq_;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double vkp = v[k][P], vkq = v[k][Q];
-        v[k][P] = c * vkp - s * vkq;
-        v[k][Q] = s * vkp + c * vkq;
-    }
-}
-
-__device__ __forceinline__ bool off_diagonal_negligible(const double (&a)[4][4]) {
-    bool done = true;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int q = p + 1; q < 4; ++q) done = done && (a[p][q] * a[p][q] <= 1e-36 * fabs(a[p][p] * a[q][q]));
-    return done;
-}
 
 // GLUE: points are heatmap-pixel keypoints and conf the raw confidences; the kernel normalises the
 // confidences over the views (+1e-5), scales the keypoints to image pixels, stores both, and triangulates
@@ -146,37 +77,11 @@ __global__ __launch_bounds__(kThreads) void triangulate_dlt(const float* __restr
 #pragma unroll
         for (int q = 0; q < p; ++q) g[p][q] = g[q][p];
 
-    double e[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e[p][q] = (p == q) ? 1.0 : 0.0;
-
-    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
-        if (off_diagonal_negligible(g)) break;
-        jacobi_rotate<0, 1>(g, e);
-        jacobi_rotate<0, 2>(g, e);
-        jacobi_rotate<0, 3>(g, e);
-        jacobi_rotate<1, 2>(g, e);
-        jacobi_rotate<1, 3>(g, e);
-        jacobi_rotate<2, 3>(g, e);
-    }
-
-    // column of the smallest eigenvalue
-    double best = g[0][0];
-    double h0 = e[0][0], h1 = e[1][0], h2 = e[2][0], h3 = e[3][0];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-        const bool take = g[q][q] < best;
-        best = take ? g[q][q] : best;
-        h0 = take ? e[0][q] : h0;
-        h1 = take ? e[1][q] : h1;
-        h2 = take ? e[2][q] : h2;
-        h3 = take ? e[3][q] : h3;
-    }
-    out[idx * 3 + 0] = static_cast<float>(h0 / h3);
-    out[idx * 3 + 1] = static_cast<float>(h1 / h3);
-    out[idx * 3 + 2] = static_cast<float>(h2 / h3);
+    double h[4];
+    smallest_eigenvector(g, h);
+    out[idx * 3 + 0] = static_cast<float>(h[0] / h[3]);
+    out[idx * 3 + 1] = static_cast<float>(h[1] / h[3]);
+    out[idx * 3 + 2] = static_cast<float>(h[2] / h[3]);
 }
 
 __global__ __launch_bounds__(256) void project_points(const float* __restrict__ proj, const float* __restrict__ pts,

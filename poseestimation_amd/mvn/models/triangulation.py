@@ -1,7 +1,7 @@
-"""AlgebraicTriangulationNet and VolumetricTriangulationNet with the reference's constructor and
-`forward(images, proj_matricies, batch)` signatures and return tuples
-(reference: mvn/models/triangulation.py:151-236 and :240-403), running the triangulation maths on the
-mvx HIP kernels.
+"""RANSACTriangulationNet, AlgebraicTriangulationNet and VolumetricTriangulationNet with the reference's
+constructor and `forward(images, proj_matricies, batch)` signatures and return tuples
+(reference: mvn/models/triangulation.py:19-148, :151-236 and :240-403), running the triangulation maths on
+the mvx HIP kernels.
 
 The heatmap backbone and the V2V volume network are not part of this package: they are taken from the
 reference's own `mvn.models.pose_resnet` / `mvn.models.v2v` when that tree is importable, or passed in
@@ -9,6 +9,7 @@ reference's own `mvn.models.pose_resnet` / `mvn.models.v2v` when that tree is im
 reference's, so its checkpoints load with strict=True.  Forward-only: the triangulation ops record no
 autograd graph (the reference's algebraic path is not differentiable either, mvn/utils/multiview.py:166).
 """
+import random
 import time
 
 import numpy as np
@@ -43,6 +44,124 @@ def _reference_volume_net(in_channels, out_channels):
 def _sync(device):
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
+
+
+def draw_view_pairs(n_points, n_views, n_iters):
+    """(n_points, n_iters, 2) uint8 view pairs drawn exactly as the reference draws them: for each point in
+    order, `n_iters` calls of `sorted(random.sample(views, 2))` on Python's global generator
+    (mvn/models/triangulation.py:96-97), so that `random.seed(s)` before a forward gives the reference's
+    hypotheses.  (The reference samples from a set, which Python 3.11 no longer accepts; a range of the same
+    length consumes the generator identically.)"""
+    views = range(n_views)
+    sample = random.sample
+    pairs = np.empty((n_points, n_iters, 2), dtype=np.uint8)
+    for p in range(n_points):
+        for i in range(n_iters):
+            a, b = sample(views, 2)
+            pairs[p, i, 0], pairs[p, i, 1] = (a, b) if a < b else (b, a)
+    return pairs
+
+
+def all_view_pairs(n_points, n_views):
+    """Every unordered view pair, the same for each point: a deterministic superset of what random sampling can
+    draw (needs no host random numbers; not the reference's behaviour)."""
+    pairs = np.array([(a, b) for a in range(n_views) for b in range(a + 1, n_views)], dtype=np.uint8)
+    return np.broadcast_to(pairs, (n_points,) + pairs.shape)
+
+
+def ransac_triangulate_batch(proj_matricies, keypoints_2d, view_pairs, reprojection_error_epsilon=15.0,
+                             direct_optimization=True):
+    """RANSAC triangulation of every (frame, joint) in one launch.
+
+    proj_matricies (B, V, 3, 4) and keypoints_2d (B, V, J, 2) on a HIP device; view_pairs (B * J, n_iters, 2)
+    uint8 (numpy or tensor).  Returns (keypoints_3d (B, J, 3) float64, inlier_masks (B, J) int32 bit masks)."""
+    proj = _cabi.device_f32(proj_matricies, "proj_matricies")
+    if not (torch.is_tensor(keypoints_2d) and keypoints_2d.is_cuda):
+        raise _cabi.MvxError("keypoints_2d must be a tensor on a HIP device (no CPU path)")
+    b, v, j = keypoints_2d.shape[:3]
+    if tuple(proj.shape) != (b, v, 3, 4):
+        raise ValueError("proj_matricies must have shape %s, got %s" % ((b, v, 3, 4), tuple(proj.shape)))
+    if not 2 <= v <= 32:
+        raise ValueError("RANSAC triangulation takes 2 to 32 views, got %d" % v)
+    points = keypoints_2d.to(torch.float64).contiguous()
+    pairs = torch.as_tensor(np.ascontiguousarray(view_pairs) if isinstance(view_pairs, np.ndarray) else view_pairs)
+    if pairs.dtype != torch.uint8 or pairs.dim() != 3 or pairs.shape[0] != b * j or pairs.shape[2] != 2:
+        raise ValueError("view_pairs must be uint8 of shape (%d, n_iters, 2), got %s %s"
+                         % (b * j, pairs.dtype, tuple(pairs.shape)))
+    pairs = pairs.to(proj.device).contiguous()
+    out = torch.empty((b, j, 3), dtype=torch.float64, device=proj.device)
+    masks = torch.empty((b, j), dtype=torch.int32, device=proj.device)
+    with torch.cuda.device(proj.device):
+        st = _cabi.load().mvx_triangulate_ransac(
+            _cabi.ptr(proj), _cabi.ptr(points), _cabi.ptr(pairs), b, v, j, int(pairs.shape[1]),
+            float(reprojection_error_epsilon), int(bool(direct_optimization)), _cabi.ptr(out), _cabi.ptr(masks),
+            _cabi.stream(proj.device))
+    _cabi.check(st, "mvx_triangulate_ransac")
+    return out, masks
+
+
+class RANSACTriangulationNet(nn.Module):
+    """Heatmap arg-max keypoints, then RANSAC over view pairs, DLT over the inliers and (with
+    config.model.direct_optimization) a Huber-loss refinement.  Reference: mvn/models/triangulation.py:19-148.
+
+    `view_pairs="sampled"` (default) draws the hypotheses from Python's `random` like the reference, one host
+    draw per (frame, joint, iteration); `view_pairs="all"` tests every pair instead and needs no host work."""
+
+    def __init__(self, config, device='cuda:0', backbone=None, view_pairs="sampled"):
+        super().__init__()
+        config.model.backbone.alg_confidences = False
+        config.model.backbone.vol_confidences = False
+        self.backbone = backbone if backbone is not None else _reference_backbone(config.model.backbone, device)
+        self.direct_optimization = config.model.direct_optimization
+        if view_pairs not in ("sampled", "all"):
+            raise ValueError("view_pairs must be 'sampled' or 'all', got %r" % (view_pairs,))
+        self.view_pairs = view_pairs
+
+    def keypoints_from_heatmaps(self, heatmaps, image_shape):
+        """(B, V, J, h, w) heatmaps -> (B, V, J, 2) int64 keypoints in image pixels (triangulation.py:48-56)."""
+        hm = _cabi.device_f32(heatmaps, "heatmaps")
+        b, v, j, h, w = hm.shape
+        keypoints = torch.empty((b, v, j, 2), dtype=torch.int64, device=hm.device)
+        with torch.cuda.device(hm.device):
+            st = _cabi.load().mvx_heatmap_argmax(_cabi.ptr(hm), b * v * j, h, w, float(image_shape[1] / w),
+                                                 float(image_shape[0] / h), _cabi.ptr(keypoints),
+                                                 _cabi.stream(hm.device))
+        _cabi.check(st, "mvx_heatmap_argmax")
+        return keypoints
+
+    def forward(self, images, proj_matricies, batch):
+        batch_size, n_views = images.shape[:2]
+        images = images.view(-1, *images.shape[2:])
+        heatmaps, _, _, _ = self.backbone(images)
+        image_shape = tuple(images.shape[2:])
+        heatmaps = heatmaps.view(batch_size, n_views, *heatmaps.shape[1:])
+        n_joints = heatmaps.shape[2]
+        with torch.no_grad():
+            keypoints_2d = self.keypoints_from_heatmaps(heatmaps, image_shape)
+            if self.view_pairs == "sampled":
+                pairs = draw_view_pairs(batch_size * n_joints, n_views, 10)
+            else:
+                pairs = all_view_pairs(batch_size * n_joints, n_views)
+            keypoints_3d, _ = ransac_triangulate_batch(proj_matricies, keypoints_2d, pairs, 15.0,
+                                                       self.direct_optimization)
+        confidences = torch.zeros((batch_size, n_views, n_joints), dtype=torch.float32, device=images.device)
+        return keypoints_3d.float(), keypoints_2d, heatmaps, confidences
+
+    def triangulate_ransac(self, proj_matricies, points, n_iters=10, reprojection_error_epsilon=15,
+                           direct_optimization=True):
+        """One point from (V, 3, 4) projections and (V, 2) keypoints (array-likes) -> (point (3,) float64 numpy,
+        sorted inlier view indices).  Reference: mvn/models/triangulation.py:83-148."""
+        assert len(proj_matricies) == len(points)
+        assert len(points) >= 2
+        device = torch.device("cuda", torch.cuda.current_device())
+        # float32 projections, which is what forward hands the reference's numpy code as well
+        proj = torch.as_tensor(np.asarray(proj_matricies, dtype=np.float32), device=device)[None]
+        pts = torch.as_tensor(np.asarray(points, dtype=np.float64), device=device)[None, :, None, :]
+        pairs = draw_view_pairs(1, len(points), n_iters)
+        out, mask = ransac_triangulate_batch(proj, pts, pairs, reprojection_error_epsilon, direct_optimization)
+        bits = int(mask.item()) & 0xffffffff
+        inliers = np.array([v for v in range(len(points)) if (bits >> v) & 1])
+        return out[0, 0].cpu().numpy(), inliers
 
 
 class AlgebraicTriangulationNet(nn.Module):

@@ -1,0 +1,94 @@
+"""The steps the real-time pipelines run on every frame after triangulation (reference:
+real_pipeline_trt.py:349-399, pipeline_video.py:399-411): keep the recent poses, smooth them, and turn the
+result into the messages sent to the renderer.  The poses stay on the device; one launch produces both frames
+of a message pair and one small copy brings them to the host.  Sockets and queues (send_msg.py) are not part of
+this module: `encode` returns the bytes the reference hands to its socket.
+"""
+import json
+
+import numpy as np
+import torch
+
+from poseestimation_amd import _cabi
+from poseestimation_amd.savgol_filer import fit_window, hat_matrix
+
+# joint names in wire order and the model joint each one is read from (real_pipeline_trt.py:133-135, :472)
+UNITY_JOINTS = ('Hip', 'RightHip', 'RightKnee', 'RightAnkle', 'LeftHip', 'LeftKnee', 'LeftAnkle', 'Spine', 'Thorax',
+                'Neck', 'Head', 'LeftShoulder', 'LeftElbow', 'LeftWrist', 'RightShoulder', 'RightElbow', 'RightWrist')
+POINT_CHANGE = (6, 2, 1, 0, 3, 4, 5, 7, 8, 16, 9, 13, 14, 15, 12, 11, 10)
+
+
+def unity_points(points, scale=1.0, order=POINT_CHANGE):
+    """points (..., J, 3) float32 on a HIP device -> joints reordered, axes (x, y, z) -> (-x, z, -y), times scale."""
+    p = _cabi.device_f32(points, "points")
+    n_joints = p.shape[-2]
+    order_t = torch.tensor(order, dtype=torch.int32, device=p.device)
+    if order_t.numel() != n_joints or int(order_t.min()) < 0 or int(order_t.max()) >= n_joints:
+        raise ValueError("order must list %d joint indices below %d" % (n_joints, n_joints))
+    out = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        st = _cabi.load().mvx_unity_points(_cabi.ptr(p), _cabi.ptr(order_t), p.numel() // (n_joints * 3), n_joints,
+                                           float(scale), _cabi.ptr(out), _cabi.stream(p.device))
+    _cabi.check(st, "mvx_unity_points")
+    return out
+
+
+class RealtimeTail:
+    """Per-frame state of a real-time pipeline: `push(keypoints_3d)` takes the (J, 3) pose of the new frame (on
+    the device) and returns the list of wire messages for it, as the reference builds them: one message until
+    more than `slide_window_size` frames have been seen, then two per frame (the mean of the last two smoothed
+    poses, then the last smoothed pose; the window is the last `window_frames` = 8 poses, filtered with
+    SAVGOLFilter(slide_window_size)).  The scale is 0.43 over the length of the bone between wire joints 2 and 3
+    in the first frame (real_pipeline_trt.py:386-392)."""
+
+    def __init__(self, slide_window_size=8, window_frames=8, unity_len=0.43, names=UNITY_JOINTS, order=POINT_CHANGE):
+        self.slide_window_size = slide_window_size
+        self.window_frames = window_frames
+        self.unity_len = unity_len
+        self.names = tuple(names)
+        self.order = tuple(order)
+        self.frames_seen = 0
+        self.scale = None
+        self._ring = None          # (window_frames, J, 3) on the device, oldest first
+        self._order_t = None
+
+    def _setup(self, pose):
+        n_joints = pose.shape[0]
+        self._ring = torch.zeros((self.window_frames, n_joints, 3), dtype=torch.float32, device=pose.device)
+        self._order_t = torch.tensor(self.order, dtype=torch.int32, device=pose.device)
+
+    def push(self, keypoints_3d):
+        pose = _cabi.device_f32(keypoints_3d, "keypoints_3d").reshape(-1, 3)
+        if self._ring is None:
+            self._setup(pose)
+        self._ring = torch.roll(self._ring, -1, 0)
+        self._ring[-1] = pose
+        self.frames_seen += 1
+        n_joints = pose.shape[0]
+        if self.scale is None:
+            first = unity_points(pose, 1.0, self.order).cpu().numpy()
+            self.scale = np.float32(self.unity_len) / np.float32(np.linalg.norm(first[2] - first[3]))
+        # the reference filters once its frame counter (= poses stored, the new one included) exceeds the window size
+        if self.frames_seen > self.slide_window_size and self.frames_seen >= self.window_frames:
+            window, order = fit_window(self.slide_window_size, self.window_frames)
+            hat = hat_matrix(window, order, pose.device)
+            out = torch.empty((2, n_joints, 3), dtype=torch.float32, device=pose.device)
+            with torch.cuda.device(pose.device):
+                st = _cabi.load().mvx_realtime_tail(_cabi.ptr(self._ring), self.window_frames, n_joints, _cabi.ptr(hat),
+                                                    window, _cabi.ptr(self._order_t), float(self.scale), _cabi.ptr(out),
+                                                    _cabi.stream(pose.device))
+            _cabi.check(st, "mvx_realtime_tail")
+            host = out.cpu().numpy()
+        else:
+            host = unity_points(pose, float(self.scale), self.order).cpu().numpy()[None]
+        return [self.message(frame) for frame in host]
+
+    def message(self, wire_points):
+        """(J, 3) array already in wire order and scale -> {joint name: [x, y, z]} of Python floats."""
+        return {self.names[j]: [float(wire_points[j][0]), float(wire_points[j][1]), float(wire_points[j][2])]
+                for j in range(len(self.names))}
+
+    @staticmethod
+    def encode(message):
+        """The bytes the reference's SendMsg thread writes to its socket (send_msg.py:49-50)."""
+        return json.dumps(message).encode('utf-8')

@@ -1,0 +1,154 @@
+"""CPU tests of the rows either side of the triangulation kernels: the oracle's RANSAC and Savitzky-Golay
+restatements against the vectors the reference produced, and the host-side mirrors (data-loader glue, view-pair
+drawing, filter window rules) against the reference's outputs."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import mvn_oracle as orc
+from poseestimation_amd import _cabi
+from poseestimation_amd.mvn.datasets import utils as data_utils
+from poseestimation_amd.mvn.models.triangulation import all_view_pairs, draw_view_pairs
+from poseestimation_amd.mvn.utils import multiview
+from poseestimation_amd.savgol_filer import fit_window
+
+
+def load(name):
+    return np.load(os.path.join(gc.GOLDEN_DIR, name + ".npz"))
+
+
+# ---- RANSAC --------------------------------------------------------------------------------------------------
+def test_ransac_oracle_matches_reference():
+    g = load("ransac")
+    case = gc.ransac_inputs()
+    hm, proj, kp = case["heatmaps"], case["proj"], case["keypoints"]
+    assert gc.sha(hm, proj, kp) == str(g["input_sha"])
+    B, V, J = kp.shape[:3]
+    for direct, tag in ((False, "dlt"), (True, "refined")):
+        random.seed(gc.RANSAC_RANDOM_SEED)
+        pairs = draw_view_pairs(B * J, V, 10)
+        pts, masks = orc.ransac_batch(proj, kp, pairs, 15, direct)
+        assert np.array_equal(masks, g["masks_" + tag])
+        # without refinement: the same float64 SVD; with it: scipy's trust-region iteration stops at ftol = 1e-8
+        # and moves by a few 1e-4 mm under rounding-level changes of the residuals
+        tol = 2e-3 if direct else 1e-7
+        assert np.abs(pts - g["points_" + tag]).max() < tol
+    # some hypotheses must actually have rejected the corrupted view, or the fixture tests nothing
+    assert (g["masks_dlt"] != 15).sum() >= 10
+
+
+def test_ransac_oracle_forward_keypoints():
+    g = load("ransac")
+    hm = gc.ransac_inputs()["heatmaps"]
+    assert np.array_equal(orc.heatmap_argmax_keypoints(hm, (384, 384)), g["forward_kp2d"])
+    assert g["forward_conf"].shape == hm.shape[:3] and not g["forward_conf"].any()
+
+
+def test_heatmap_argmax_oracle_truncates_like_torch():
+    rng = np.random.default_rng(2)
+    hm = rng.standard_normal((1, 2, 3, 7, 9)).astype(np.float32)
+    hm[0, 0, 0, 3, 4] = np.nan
+    hm[0, 1, 1] = 0.25                                   # all equal: first index
+    got = orc.heatmap_argmax_keypoints(hm, (50, 100))
+    t = torch.from_numpy(hm)
+    _, mi = torch.max(t.view(1, 2, 3, -1), dim=-1)
+    kp = torch.stack([mi % 9, mi // 9], dim=-1)
+    ref = torch.zeros_like(kp)
+    ref[..., 0] = kp[..., 0] * (100 / 9)
+    ref[..., 1] = kp[..., 1] * (50 / 7)
+    assert np.array_equal(got, ref.numpy())
+    assert got[0, 0, 0].tolist() == [int(np.float32(4) * np.float32(100 / 9)), int(np.float32(3) * np.float32(50 / 7))]
+
+
+def test_draw_view_pairs_follows_python_random():
+    random.seed(9)
+    pairs = draw_view_pairs(5, 4, 10)
+    random.seed(9)
+    expect = [[sorted(random.sample(range(4), 2)) for _ in range(10)] for _ in range(5)]
+    assert pairs.dtype == np.uint8 and pairs.tolist() == expect
+    every = all_view_pairs(3, 4)
+    assert every.shape == (3, 6, 2) and every[1].tolist() == [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]
+
+
+# ---- temporal filter ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("i", range(len(gc.SAVGOL_CASES)))
+def test_savgol_oracle_matches_reference(i):
+    g = load("savgol")
+    x = gc.savgol_input(i)
+    T, window_size = gc.SAVGOL_CASES[i]
+    y = orc.savgol_smooth(x, window_size)
+    ref = g["y%d" % i]
+    assert ref.dtype == np.float32 and ref.shape == x.shape
+    # float64 here, float32 storage there: half a float32 ulp of values up to a few thousand
+    assert np.abs(y - ref).max() <= 2.0 ** -12
+    assert fit_window(window_size, T) == orc.savgol_window(window_size, T)
+
+
+def test_savgol_oracle_against_scipy_directly():
+    from scipy.signal import savgol_filter
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((50, 6)) * 100
+    for window, order in ((5, 2), (11, 3), (50, 2), (7, 1)):
+        if window % 2 == 0 and window != len(x):
+            continue
+        np.testing.assert_allclose(orc.savgol_filter(x, window, order), savgol_filter(x, window, order, axis=0),
+                                   rtol=0, atol=1e-9)
+
+
+def test_unity_restatement_shapes():
+    rng = np.random.default_rng(6)
+    pts = rng.uniform(-900, 900, (17, 3)).astype(np.float32)
+    wire = orc.unity_points(pts)
+    assert np.array_equal(wire[0], np.array([-pts[6, 0], pts[6, 2], -pts[6, 1]], dtype=np.float32))
+    scale = orc.unity_scale(pts)
+    msg = orc.unity_message(pts, scale)
+    assert list(msg) == list(orc.UNITY_JOINTS) and all(isinstance(v, float) for v in msg["Head"])
+    assert abs(np.linalg.norm(np.array(msg["RightKnee"]) - np.array(msg["RightAnkle"])) - 0.43) < 1e-6
+
+
+# ---- data-loader glue --------------------------------------------------------------------------------------------
+def test_collate_and_prepare_batch_match_reference():
+    g = load("datasets")
+    items = gc.dataset_items(multiview.Camera)
+    for rand, tag in ((True, "rand"), (False, "all")):
+        np.random.seed(5)
+        batch = data_utils.make_collate_fn(rand, 3, 6)(items + [None])
+        assert set(batch) == {"images", "detections", "cameras", "keypoints_3d", "indexes", "actname", "pred_keypoints_3d"}
+        images, kp, validity, proj = data_utils.prepare_batch(batch, "cpu", None)
+        assert gc.sha(images.numpy()) == str(g["images_sha_" + tag])
+        assert np.array_equal(batch["detections"], g["detections_" + tag])
+        assert np.array_equal(kp.numpy(), g["kp_" + tag]) and np.array_equal(validity.numpy(), g["validity_" + tag])
+        assert proj.dtype == torch.float32 and np.array_equal(proj.numpy(), g["proj_" + tag])
+        np.random.seed(6)
+        batch = data_utils.make_collate_fn_test(rand, 3, 6)(items)
+        assert set(batch) == {"images", "detections", "cameras", "indexes"}
+        images, proj = data_utils.prepare_batch_test(batch, "cpu", None)
+        assert gc.sha(images.numpy()) == str(g["test_images_sha_" + tag])
+        assert np.array_equal(proj.numpy(), g["test_proj_" + tag])
+    sample = {"inps": [torch.from_numpy(im.transpose(2, 0, 1).copy()).float() for im in items[0]["images"][:4]],
+              "cameras": items[0]["cameras"][:4]}
+    images, proj = data_utils.prepare_batch_video(sample, 4, "cpu")
+    assert tuple(images.shape) == (1, 4, 3, 8, 10) and gc.sha(images.numpy()) == str(g["video_images_sha"])
+    assert np.array_equal(proj.numpy(), g["video_proj"])
+    with pytest.raises(ValueError):
+        data_utils.prepare_batch_video(sample, 2, "cpu")
+    assert data_utils.make_collate_fn()([None, None]) is None
+
+
+def test_new_entry_points_validate_arguments_without_a_gpu():
+    lib = _cabi.load()
+    assert lib.mvx_heatmap_argmax(None, -1, 4, 4, 1.0, 1.0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_heatmap_argmax(None, 0, 4, 4, 1.0, 1.0, None, None) == _cabi.MVX_OK
+    assert lib.mvx_triangulate_ransac(None, None, None, 1, 1, 17, 10, 15.0, 1, None, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert b"n_views" in lib.mvx_last_error()
+    assert lib.mvx_triangulate_ransac(None, None, None, 1, 33, 17, 10, 15.0, 1, None, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_triangulate_ransac(None, None, None, 0, 4, 17, 10, 15.0, 1, None, None, None) == _cabi.MVX_OK
+    assert lib.mvx_savgol_filter(None, 8, 51, None, 6, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT   # even window
+    assert lib.mvx_savgol_filter(None, 5, 51, None, 7, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT   # longer than T
+    assert lib.mvx_savgol_filter(None, 0, 51, None, 7, None, None) == _cabi.MVX_OK
+    assert lib.mvx_realtime_tail(None, 1, 17, None, 1, None, 1.0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_unity_points(None, None, -1, 17, 1.0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT

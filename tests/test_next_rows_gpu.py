@@ -1,0 +1,270 @@
+"""HIP kernels of the rows either side of the triangulation kernels (RANSAC triangulation, temporal filter, wire
+format) against the oracle and the reference's golden vectors, through the C ABI and the mirrors.
+
+Tolerances.  Arg-max keypoints and inlier sets: exact.  RANSAC points without refinement: 1e-6 mm (float64 Jacobi
+eigenvector against float64 LAPACK SVD).  With the Huber refinement the reference's own answer is only defined
+up to scipy's stopping rule: at its default ftol = 1e-8 least_squares stops up to 1.3e-2 mm short of the minimiser
+on these fixtures (measured by running it again with 1e-15 tolerances), and two CPU evaluations of the same
+residuals already differ by 3e-4 mm.  The kernel iterates to the minimiser, so the checks are: cost not above the
+reference's nor above the tightly converged scipy solution's (whose finite-difference Jacobian leaves it 5e-5 mm
+and 1e-12 in cost short), within 1e-4 mm of the latter and within 2e-2 mm of the reference.  Filtered poses: one float32 rounding of a float64 sum (2^-12 mm at these magnitudes)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import mvn_oracle as orc
+from poseestimation_amd import _cabi, synth
+from poseestimation_amd.mvn.models import triangulation as tri
+from poseestimation_amd.realtime import POINT_CHANGE, UNITY_JOINTS, RealtimeTail, unity_points
+from poseestimation_amd.savgol_filer import SAVGOLFilter, fit_window, savgol_device
+
+pytestmark = pytest.mark.gpu
+
+REFINED_MM_TOL = 2e-2
+MINIMISER_MM_TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def load(name):
+    return np.load(os.path.join(gc.GOLDEN_DIR, name + ".npz"))
+
+
+class _Stub(torch.nn.Module):
+    def __init__(self, heatmaps):
+        super().__init__()
+        self.heatmaps = heatmaps
+
+    def forward(self, images):
+        return self.heatmaps, None, None, None
+
+
+def _ransac_net(heatmaps=None, direct=True, view_pairs="sampled"):
+    from types import SimpleNamespace as NS
+    cfg = NS(model=NS(backbone=NS(), direct_optimization=direct))
+    return tri.RANSACTriangulationNet(cfg, device=dev(), backbone=_Stub(heatmaps), view_pairs=view_pairs)
+
+
+# ---- arg-max keypoints ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,image", [((2, 4, 17, 96, 96), (384, 384)), ((1, 2, 3, 7, 9), (50, 100)),
+                                         ((3, 1, 2, 64, 64), (256, 256)), ((1, 1, 1, 1, 1), (4, 4)),
+                                         ((1, 3, 2, 33, 31), (384, 300))])
+def test_heatmap_argmax_matches_oracle(shape, image):
+    rng = np.random.default_rng(sum(shape))
+    hm = rng.standard_normal(shape).astype(np.float32)
+    if hm.size > 100:
+        hm[0, 0, 0].flat[5] = hm[0, 0, 0].max() + 1.0          # maximum early in the map
+        hm[0, 0, 1] = 0.5                                       # constant map: first index
+        hm[0, -1, -1].flat[-1] = 99.0                           # maximum in the last element
+        hm[0, -1, 0].flat[[7, 11]] = np.nan                     # NaN wins, first NaN
+        hm[0, 0, -1].flat[[3, 17]] = 50.0                       # tie: lower index
+    net = _ransac_net()
+    got = net.keypoints_from_heatmaps(to_dev(hm), image).cpu().numpy()
+    assert got.dtype == np.int64
+    assert np.array_equal(got, orc.heatmap_argmax_keypoints(hm, image))
+
+
+def test_heatmap_argmax_unaligned_view():
+    """A map pointer that is not 16-byte aligned takes the scalar-load kernel."""
+    rng = np.random.default_rng(8)
+    flat = to_dev(rng.standard_normal(1 + 2 * 3 * 5 * 8 * 8).astype(np.float32))
+    hm = flat[1:].view(2, 3, 5, 8, 8)
+    keypoints = torch.empty((2, 3, 5, 2), dtype=torch.int64, device=dev())
+    st = _cabi.load().mvx_heatmap_argmax(_cabi.ptr(hm), 30, 8, 8, 4.0, 4.0, _cabi.ptr(keypoints), _cabi.stream(dev()))
+    _cabi.check(st, "mvx_heatmap_argmax")
+    assert np.array_equal(keypoints.cpu().numpy(), orc.heatmap_argmax_keypoints(hm.cpu().numpy(), (32, 32)))
+
+
+# ---- RANSAC ----------------------------------------------------------------------------------------------------
+def test_ransac_points_match_reference():
+    g = load("ransac")
+    case = gc.ransac_inputs()
+    proj, kp = case["proj"], case["keypoints"]
+    B, V, J = kp.shape[:3]
+    for direct, tag in ((False, "dlt"), (True, "refined")):
+        random.seed(gc.RANSAC_RANDOM_SEED)
+        pairs = tri.draw_view_pairs(B * J, V, 10)
+        pts, masks = tri.ransac_triangulate_batch(to_dev(proj), to_dev(kp), pairs, 15, direct)
+        pts, masks = pts.cpu().numpy(), masks.cpu().numpy()
+        assert pts.dtype == np.float64
+        assert np.array_equal(masks, g["masks_" + tag])
+        ref = g["points_" + tag]
+        if not direct:
+            assert np.abs(pts - ref).max() < 1e-6
+            continue
+        assert np.abs(pts - ref).max() < REFINED_MM_TOL
+        for b in range(B):
+            for j in range(J):
+                idx = [v for v in range(V) if (masks[b, j] >> v) & 1]
+                mine = orc.huber_cost(pts[b, j], kp[b, idx, j], proj[b, idx])
+                theirs = orc.huber_cost(ref[b, j], kp[b, idx, j], proj[b, idx])
+                assert mine <= theirs * (1 + 1e-12) + 1e-14
+                tight = orc.huber_minimiser(g["points_dlt"][b, j], kp[b, idx, j], proj[b, idx])
+                assert np.abs(pts[b, j] - tight).max() < MINIMISER_MM_TOL
+                assert mine <= orc.huber_cost(tight, kp[b, idx, j], proj[b, idx]) * (1 + 1e-13) + 1e-15
+
+
+def test_ransac_forward_matches_reference():
+    g = load("ransac")
+    case = gc.ransac_inputs()
+    hm, proj = case["heatmaps"], case["proj"]
+    B, V, J, h, w = hm.shape
+    for direct, tag in ((False, "dlt"), (True, "refined")):
+        net = _ransac_net(to_dev(hm).view(B * V, J, h, w), direct)
+        random.seed(gc.RANSAC_RANDOM_SEED + 1)
+        kp3d, kp2d, hm_out, conf = net(torch.zeros(B, V, 3, 384, 384, device=dev()), to_dev(proj), None)
+        assert kp3d.dtype == torch.float32 and tuple(kp3d.shape) == (B, J, 3)
+        assert kp2d.dtype == torch.int64 and np.array_equal(kp2d.cpu().numpy(), g["forward_kp2d"])
+        assert tuple(hm_out.shape) == (B, V, J, h, w) and torch.equal(hm_out.cpu(), torch.from_numpy(hm))
+        assert conf.dtype == torch.float32 and np.array_equal(conf.cpu().numpy(), g["forward_conf"])
+        tol = REFINED_MM_TOL if direct else 1e-3     # float32 outputs: half an ulp at metres is 6e-5 mm
+        assert np.abs(kp3d.cpu().numpy() - g["forward_kp3d_" + tag]).max() < tol
+
+
+def test_triangulate_ransac_single_point_api():
+    case = gc.ransac_inputs()
+    proj, kp = case["proj"], case["keypoints"]
+    net = _ransac_net()
+    for j in (0, 3, 7):
+        random.seed(50 + j)
+        point, inliers = net.triangulate_ransac(proj[1], kp[1, :, j], direct_optimization=False)
+        random.seed(50 + j)
+        pairs = tri.draw_view_pairs(1, 4, 10)[0]
+        ref, ref_inliers = orc.triangulate_ransac(proj[1], kp[1, :, j], pairs, 15, False)
+        assert point.dtype == np.float64 and point.shape == (3,)
+        assert np.array_equal(inliers, ref_inliers) and np.abs(point - ref).max() < 1e-6
+    with pytest.raises(AssertionError):
+        net.triangulate_ransac(proj[0], kp[0, :3, 0])
+    with pytest.raises(AssertionError):
+        net.triangulate_ransac(proj[0, :1], kp[0, :1, 0])
+
+
+def test_ransac_many_views_and_all_pairs():
+    """Sixteen views with three corrupted ones, every pair as hypothesis: the corrupted views are rejected and the
+    points agree with the oracle run on the same pairs."""
+    rng = np.random.default_rng(31)
+    case = synth.algebraic_case(1290, 2, 16)
+    proj = case["proj"]
+    kp = orc.heatmap_argmax_keypoints(case["heatmaps"], (384, 384))
+    bad = [2, 9, 13]
+    kp[:, bad] += rng.integers(60, 150, size=kp[:, bad].shape)
+    pairs = tri.all_view_pairs(2 * 17, 16)
+    pts, masks = tri.ransac_triangulate_batch(to_dev(proj), to_dev(kp), pairs, 15, False)
+    ref, ref_masks = orc.ransac_batch(proj, kp, pairs, 15, False)
+    assert np.array_equal(masks.cpu().numpy(), ref_masks)
+    assert np.abs(pts.cpu().numpy() - ref).max() < 1e-6
+    good = sum(1 << v for v in range(16) if v not in bad)
+    assert ((masks.cpu().numpy() & good) == good).mean() > 0.9
+    assert all(((masks.cpu().numpy() >> v) & 1).mean() < 0.1 for v in bad)
+
+
+def test_ransac_batch_size_and_degenerate_pairs():
+    """4096 frames in one launch against the oracle on a slice; pairs naming a view that does not exist are
+    skipped, and with no valid pair at all every view is used."""
+    case = synth.algebraic_case(1291, 64, 4)
+    proj = np.tile(case["proj"], (64, 1, 1, 1))
+    kp = np.tile(orc.heatmap_argmax_keypoints(case["heatmaps"], (384, 384)), (64, 1, 1, 1))
+    B, V, J = kp.shape[:3]
+    assert B == 4096
+    random.seed(3)
+    pairs = tri.draw_view_pairs(64 * J, V, 10)
+    pairs = np.tile(pairs, (64, 1, 1))
+    pts, masks = tri.ransac_triangulate_batch(to_dev(proj), to_dev(kp), pairs, 15, True)
+    pts = pts.cpu().numpy()
+    assert np.array_equal(pts[:64], pts[-64:])                       # same inputs, same results
+    ref, ref_masks = orc.ransac_batch(proj[:4], kp[:4], pairs[:4 * J], 15, True)
+    assert np.array_equal(masks.cpu().numpy()[:4], ref_masks)
+    assert np.abs(pts[:4] - ref).max() < REFINED_MM_TOL
+    bogus = np.full((4 * J, 3, 2), 200, dtype=np.uint8)
+    pts2, masks2 = tri.ransac_triangulate_batch(to_dev(proj[:4]), to_dev(kp[:4]), bogus, 15, False)
+    assert (masks2.cpu().numpy() == 15).all()
+    full, _ = orc.ransac_batch(proj[:4], kp[:4], np.zeros((4 * J, 0, 2), dtype=np.uint8), 15, False)
+    assert np.abs(pts2.cpu().numpy() - full).max() < 1e-6
+
+
+def test_ransac_argument_errors():
+    proj = torch.zeros(1, 4, 3, 4, device=dev())
+    kp = torch.zeros(1, 4, 17, 2, dtype=torch.int64, device=dev())
+    with pytest.raises(ValueError, match="view_pairs"):
+        tri.ransac_triangulate_batch(proj, kp, np.zeros((3, 10, 2), dtype=np.uint8))
+    with pytest.raises(ValueError, match="proj_matricies"):
+        tri.ransac_triangulate_batch(proj[:, :3], kp, np.zeros((17, 10, 2), dtype=np.uint8))
+    with pytest.raises(_cabi.MvxError):
+        tri.ransac_triangulate_batch(proj, kp.cpu(), np.zeros((17, 10, 2), dtype=np.uint8))
+    with pytest.raises(ValueError, match="view_pairs"):
+        _ransac_net(view_pairs="some")
+
+
+# ---- temporal filter -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("i", range(len(gc.SAVGOL_CASES)))
+def test_savgol_filter_matches_reference(i):
+    g = load("savgol")
+    x = gc.savgol_input(i)
+    _, window_size = gc.SAVGOL_CASES[i]
+    ref = g["y%d" % i]
+    flt = SAVGOLFilter(window_size)
+    y_dev, seconds = flt(to_dev(x))
+    assert y_dev.is_cuda and y_dev.dtype == torch.float32 and seconds >= 0.0
+    y_cpu, _ = flt(torch.from_numpy(x))
+    y_np, _ = flt(x)
+    assert not y_cpu.is_cuda and isinstance(y_np, np.ndarray) and y_np.dtype == np.float32
+    assert torch.equal(y_cpu, y_dev.cpu()) and np.array_equal(y_np, y_cpu.numpy())
+    assert np.abs(y_np - ref).max() <= 2.0 ** -11                    # one float32 ulp at |x| < 4096
+    assert np.abs(y_np.astype(np.float64) - orc.savgol_smooth(x, window_size)).max() <= 2.0 ** -12
+    y64, _ = flt(x.astype(np.float64))
+    assert y64.dtype == np.float64
+
+
+def test_savgol_reproduces_quadratics_at_size():
+    """Property at a size the oracle does not run at: an order-2 filter returns any quadratic series unchanged."""
+    T, S = 200000, 51
+    t = torch.arange(T, device=dev(), dtype=torch.float64)[:, None] / T
+    coef = torch.randn(3, S, device=dev(), dtype=torch.float64)
+    x = (coef[0] + coef[1] * t + coef[2] * t * t).float().view(T, 17, 3)
+    for window in (7, 31):
+        y = savgol_device(x, window, 2)
+        assert (y - x).abs().max().item() < 2e-6
+    with pytest.raises(ValueError):
+        savgol_device(x, 8, 2)
+    with pytest.raises(AssertionError):
+        SAVGOLFilter(8)(x[:1])
+
+
+# ---- wire format -------------------------------------------------------------------------------------------------
+def test_unity_points_and_realtime_tail_match_restatement():
+    rng = np.random.default_rng(12)
+    walk = (np.cumsum(rng.standard_normal((14, 17, 3)) * 12.0, axis=0) + rng.uniform(-700, 700, (1, 17, 3))).astype(np.float32)
+    scale = orc.unity_scale(walk[0])
+    got = unity_points(to_dev(walk), float(np.float32(scale))).cpu().numpy()
+    want = np.stack([orc.unity_points(f) * np.float32(scale) for f in walk])
+    assert np.array_equal(got, want)
+    tail = RealtimeTail(slide_window_size=8)
+    for n, frame in enumerate(walk, start=1):
+        msgs = tail.push(to_dev(frame))
+        if n <= 8:
+            assert len(msgs) == 1
+            want_frames = [walk[n - 1]]
+        else:
+            assert len(msgs) == 2
+            want_frames = orc.realtime_window_frames(walk[n - 8:n])
+        for msg, frame_want in zip(msgs, want_frames):
+            ref = orc.unity_message(frame_want, np.float32(scale))
+            assert list(msg) == list(UNITY_JOINTS)
+            for name in UNITY_JOINTS:
+                assert all(isinstance(v, float) for v in msg[name])
+                # the filter's float64 sum is rounded once here; the restatement rounds the scipy-style result
+                assert np.allclose(msg[name], ref[name], rtol=0, atol=2e-7 * 4096 * float(scale))
+    assert abs(float(tail.scale) - float(scale)) < 1e-9
+    payload = RealtimeTail.encode(msgs[-1])
+    assert isinstance(payload, bytes) and payload.startswith(b'{"Hip": [')
+    assert POINT_CHANGE[0] == 6
