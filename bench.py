@@ -1,6 +1,6 @@
 """Throughput of the multi-view triangulation path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload algebraic|volumetric|stream16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload algebraic|volumetric|stream16|ransac]
 
 A step is one pass of the path over one resident batch of synthetic frames:
   algebraic  (default; BASELINE.json configs[1]) 4096 frames x 4 views x 17 joints of 96x96 heatmaps per GPU:
@@ -9,6 +9,8 @@ A step is one pass of the path over one resident batch of synthetic frames:
   volumetric (configs[2]) 64 frames: 4 views x 32-channel 96x96 features unprojected into 64^3 (softmax
              aggregation), 17 volumes per frame soft-argmaxed with coordinates (normalised volumes written).
   stream16   (configs[4]) 16 views: p50 latency of one frame and throughput at 1024 frames.
+  ransac     the reference's third triangulation model on the algebraic shapes: arg-max keypoints of 4096 x 4 x 17
+             heatmaps, then RANSAC over every view pair + DLT over the inliers + Huber refinement per joint.
 With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds its own batch (weak scaling,
 frames sharded across ranks) and each step ends with the RCCL all-gather of the (frames, 17, 3) keypoints.
 Rank 0 prints one JSON line; `value` is the whole-job frames/s with inputs resident in HBM.
@@ -194,6 +196,78 @@ def run_volumetric(args, dev, rank, world, frames=64):
     return ms, frames, roof, cfg, extra
 
 
+def cpu_baseline_ransac(sample_frames):
+    """The numpy/scipy restatement of RANSACTriangulationNet (oracle/mvn_oracle.py) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mvn_oracle
+    from poseestimation_amd.mvn.models.triangulation import all_view_pairs
+    case = synth.algebraic_case(1234 + 1, sample_frames, 4)
+    pairs = all_view_pairs(sample_frames * 17, 4)
+    t0 = time.perf_counter()
+    kp = mvn_oracle.heatmap_argmax_keypoints(case["heatmaps"], (384, 384))
+    mvn_oracle.ransac_batch(case["proj"], kp, pairs, 15, True)
+    secs = time.perf_counter() - t0
+    return {"value": sample_frames / secs, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames x 4 views x 17 joints: numpy arg-max, 6 pair hypotheses per joint with numpy SVD, "
+                      "scipy least_squares(huber) refinement; one pass" % sample_frames}
+
+
+def run_ransac(args, dev, rank, world, frames=4096):
+    from poseestimation_amd.mvn.models.triangulation import all_view_pairs
+    case = synth.device_algebraic_case(1234 + 1 + rank, frames, 4, dev)
+    hm, proj = case["heatmaps"], case["proj"]
+    b, v, j, h, w = hm.shape
+    lib = _cabi.load()
+    pairs = torch.from_numpy(np.ascontiguousarray(all_view_pairs(b * j, v))).to(dev)
+    n_iters = pairs.shape[1]
+    kp = torch.empty((b, v, j, 2), dtype=torch.int64, device=dev)
+    kp_f64 = torch.empty((b, v, j, 2), dtype=torch.float64, device=dev)
+    out = torch.empty((b, j, 3), dtype=torch.float64, device=dev)
+    kp3d = torch.empty((b, j, 3), dtype=torch.float32, device=dev)
+    masks = torch.empty((b, j), dtype=torch.int32, device=dev)
+    st = _cabi.stream(dev)
+    ka, kr = EventTimer(), EventTimer()
+
+    def launch_argmax():
+        return lib.mvx_heatmap_argmax(_cabi.ptr(hm), b * v * j, h, w, 384.0 / w, 384.0 / h, _cabi.ptr(kp), st)
+
+    def launch_ransac():
+        kp_f64.copy_(kp)
+        rc = lib.mvx_triangulate_ransac(_cabi.ptr(proj), _cabi.ptr(kp_f64), _cabi.ptr(pairs), b, v, j, n_iters, 15.0, 1,
+                                        _cabi.ptr(out), _cabi.ptr(masks), st)
+        kp3d.copy_(out)
+        return rc
+
+    def step(timed):
+        if timed:
+            with ka:
+                rc = launch_argmax()
+            with kr:
+                rc |= launch_ransac()
+        else:
+            rc = launch_argmax() | launch_ransac()
+        if rc != 0:
+            raise RuntimeError("mvx call failed: %s" % lib.mvx_last_error().decode())
+        return gather(kp3d, frames * world) if world > 1 else kp3d
+
+    got = step(False)
+    own = got[rank * frames: rank * frames + 8] if world > 1 else got[:8]
+    err = (own.cpu().numpy() - case["joints_3d"][:8]).__abs__().max()
+    assert err < 80.0, "triangulated joints are %g mm from the synthetic ground truth" % err
+    ms = timed_loop(step, args, dev, world)
+    bytes_per_launch = frames * v * j * (h * w * 4 + 16)
+    roof = {"bound": "hbm", "kernel": "heatmap_argmax<9>", "achieved": bytes_per_launch / (ka.mean_ms() * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": ka.mean_ms()}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    extra = {"ransac_kernel_and_casts_ms": kr.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err),
+             "mean_inlier_views": float(torch.bitwise_and(masks.view(-1, 1) >> torch.arange(4, device=dev), 1).sum(1).float().mean())}
+    cfg = {"workload": "ransac: heatmap arg-max + RANSAC (all 6 view pairs) + inlier DLT + Huber refinement, "
+                       "%d frames/GPU x 4 views x 17 joints, 96x96 heatmaps" % frames, "frames_per_gpu": frames,
+           "views": v, "joints": j, "parallelism": "frames sharded over %d GPU(s), all-gather of keypoints" % world}
+    return ms, frames, roof, cfg, extra
+
+
 def gather(local_kp, total_frames):
     """All-gather of the keypoints: RCCL on device tensors; in the single-GPU rehearsal, gloo on host copies."""
     if dist.get_backend() == "gloo":
@@ -243,7 +317,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="algebraic", choices=["algebraic", "volumetric", "stream16"])
+    ap.add_argument("--workload", default="algebraic", choices=["algebraic", "volumetric", "stream16", "ransac"])
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
     ap.add_argument("--no-writeback", action="store_true", help="algebraic: skip the normalised-heatmap output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -270,6 +344,9 @@ def main():
     elif args.workload == "volumetric":
         ms, frames, roof, cfg, extra = run_volumetric(args, dev, rank, world, args.frames or 64)
         metric = "volumetric frames/sec (4-view unproject to 64^3 + 3-D soft-argmax, 17 joints)"
+    elif args.workload == "ransac":
+        ms, frames, roof, cfg, extra = run_ransac(args, dev, rank, world, args.frames or 4096)
+        metric = "RANSAC-triangulated frames/sec (4-view, 17-joint)"
     else:
         ms, frames, roof, cfg, extra = run_algebraic(args, dev, rank, world, 16, args.frames or 1024, not args.no_writeback)
         metric = "triangulated frames/sec (16-view, 17-joint)"
@@ -282,6 +359,8 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         if args.workload == "volumetric":
             cpu = cpu_baseline_volumetric(4)
+        elif args.workload == "ransac":
+            cpu = cpu_baseline_ransac(16)
         else:
             cpu = cpu_baseline_algebraic(16 if args.workload == "stream16" else 4, 64 if args.workload == "stream16" else 256)
 

@@ -14,66 +14,94 @@ namespace {
 
 constexpr int kArgmaxThreads = 256;
 
-// Ordering of torch.max over a flattened map: NaN beats every number, larger beats smaller, and among equals
-// (or among NaNs) the lower index wins.
+// torch.max over a flattened map: NaN beats every number, larger beats smaller, and among equals (or among NaNs)
+// the lowest index wins.  The common case carries no NaN, so the scan keeps a strict running maximum (a NaN never
+// compares greater) and only notes whether a NaN was seen; a map with a NaN is then searched for its first one.
 struct Best {
     float v;
     int i;
 };
-__device__ __forceinline__ bool beats(float av, int ai, float bv, int bi) {
-    const bool an = av != av, bn = bv != bv;
-    if (an || bn) return an && (!bn || ai < bi);
-    return av > bv || (av == bv && ai < bi);
-}
-__device__ __forceinline__ void take(Best& b, float v, int i) {
-    if (beats(v, i, b.v, b.i)) {
-        b.v = v;
-        b.i = i;
-    }
+__device__ __forceinline__ void take(Best& b, bool& nan_seen, float v, int i) {
+    nan_seen = nan_seen || (v != v);
+    const bool up = v > b.v;
+    b.v = up ? v : b.v;
+    b.i = up ? i : b.i;
 }
 
-template <bool VEC>
+// NV > 0: the map is exactly NV * 256 float4 and every load is issued before the first comparison;
+// NV == 0: 16-byte loads in a loop; NV < 0: scalar loads (map size or alignment rules 16-byte loads out).
+template <int NV>
 __global__ __launch_bounds__(kArgmaxThreads) void heatmap_argmax(const float* __restrict__ maps, int hw, int w,
                                                                  float scale_x, float scale_y,
                                                                  long long* __restrict__ out) {
     typedef float float4v __attribute__((ext_vector_type(4)));
+    constexpr int kNone = 0x7fffffff;
     const int tid = threadIdx.x;
     const float* map = maps + static_cast<size_t>(blockIdx.x) * hw;
-    Best best{-INFINITY, 0x7fffffff};
-    if (VEC) {
+    Best best{-INFINITY, kNone};   // kNone survives only if every element is -inf (index 0 then) or NaN
+    bool nan_seen = false;
+    if (NV > 0) {
+        const float4v* m4 = reinterpret_cast<const float4v*>(map);
+        float4v f[NV > 0 ? NV : 1];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) f[k] = __builtin_nontemporal_load(m4 + k * kArgmaxThreads + tid);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = 4 * (k * kArgmaxThreads + tid);
+            take(best, nan_seen, f[k].x, i);
+            take(best, nan_seen, f[k].y, i + 1);
+            take(best, nan_seen, f[k].z, i + 2);
+            take(best, nan_seen, f[k].w, i + 3);
+        }
+    } else if (NV == 0) {
         const float4v* m4 = reinterpret_cast<const float4v*>(map);
         const int n4 = hw >> 2;
 #pragma unroll 4
         for (int i = tid; i < n4; i += kArgmaxThreads) {
             const float4v f = __builtin_nontemporal_load(m4 + i);
-            take(best, f.x, 4 * i);
-            take(best, f.y, 4 * i + 1);
-            take(best, f.z, 4 * i + 2);
-            take(best, f.w, 4 * i + 3);
+            take(best, nan_seen, f.x, 4 * i);
+            take(best, nan_seen, f.y, 4 * i + 1);
+            take(best, nan_seen, f.z, 4 * i + 2);
+            take(best, nan_seen, f.w, 4 * i + 3);
         }
     } else {
 #pragma unroll 4
-        for (int i = tid; i < hw; i += kArgmaxThreads) take(best, map[i], i);
+        for (int i = tid; i < hw; i += kArgmaxThreads) take(best, nan_seen, map[i], i);
     }
+    __shared__ float wave_v[kArgmaxThreads / 64];
+    __shared__ int wave_i[kArgmaxThreads / 64];
+    int idx;
+    if (__syncthreads_or(nan_seen)) {
+        // first NaN of the map (the second read comes from the caches)
+        int first = kNone;
+        for (int i = tid; i < hw; i += kArgmaxThreads) first = (map[i] != map[i] && i < first) ? i : first;
+        first = wave_min_i(first);
+        if ((tid & 63) == 0) wave_i[tid >> 6] = first;
+        __syncthreads();
+        idx = wave_i[0];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float ov = __shfl_xor(best.v, off);
-        const int oi = __shfl_xor(best.i, off);
-        take(best, ov, oi);
+        for (int k = 1; k < kArgmaxThreads / 64; ++k) idx = min(idx, wave_i[k]);
+    } else {
+        const float m = wave_max(best.v);
+        const int first = wave_min_i(best.v == m ? best.i : kNone);
+        if ((tid & 63) == 0) {
+            wave_v[tid >> 6] = m;
+            wave_i[tid >> 6] = first;
+        }
+        __syncthreads();
+        float bm = wave_v[0];
+        idx = wave_i[0];
+#pragma unroll
+        for (int k = 1; k < kArgmaxThreads / 64; ++k) {
+            const bool better = wave_v[k] > bm || (wave_v[k] == bm && wave_i[k] < idx);
+            bm = better ? wave_v[k] : bm;
+            idx = better ? wave_i[k] : idx;
+        }
+        idx = idx == kNone ? 0 : idx;
     }
-    __shared__ float wv[kArgmaxThreads / 64];
-    __shared__ int wi[kArgmaxThreads / 64];
-    if ((tid & 63) == 0) {
-        wv[tid >> 6] = best.v;
-        wi[tid >> 6] = best.i;
-    }
-    __syncthreads();
     if (tid == 0) {
-#pragma unroll
-        for (int k = 1; k < kArgmaxThreads / 64; ++k) take(best, wv[k], wi[k]);
-        // an empty comparison set cannot happen (hw >= 1); index -> (x, y), scaled in float32 and truncated,
-        // which is what assigning the product of an int64 tensor and a Python float into an int64 tensor does
-        const int idx = best.i == 0x7fffffff ? 0 : best.i;
+        // index -> (x, y), scaled in float32 and truncated, which is what assigning the product of an int64
+        // tensor and a Python float into an int64 tensor does
         const float x = static_cast<float>(idx % w) * scale_x;
         const float y = static_cast<float>(idx / w) * scale_y;
         out[static_cast<size_t>(blockIdx.x) * 2 + 0] = static_cast<long long>(x);
@@ -144,10 +172,11 @@ __device__ __forceinline__ double reprojection_error(const Views& vw, int v, con
     return 0.5 * sqrt(ex * ex + ey * ey);
 }
 
-// Cost 1/2 sum rho(r_v^2), r_v the reprojection error above, rho the Huber loss with unit scale
-// (rho(s) = s for s <= 1, 2 sqrt(s) - 1 beyond), with the weighted normal equations of its iteratively
-// reweighted least-squares step: H = sum w_v J_v^T J_v / 4, g = sum w_v J_v^T e_v / 4 (e_v = projection minus
-// keypoint, r_v = |e_v| / 2, w_v = rho'(r_v^2)).
+// Cost 1/2 sum rho(s_v), s_v = r_v^2, r_v the reprojection error above, rho the Huber loss with unit scale
+// (rho(s) = s for s <= 1, 2 sqrt(s) - 1 beyond), with its gradient g = sum w_v J_v^T e_v / 4 and the Gauss-Newton
+// Hessian of the robust cost H = sum w_v (J_v^T J_v / 4 - [s_v > 1] q_v q_v^T / (16 s_v)), where e_v = projection
+// minus keypoint, r_v = |e_v| / 2, w_v = rho'(s_v), q_v = J_v^T e_v: beyond the quadratic zone the loss is flat
+// along the residual's own direction, which the second term removes (H stays positive semi-definite).
 struct Normal {
     double cost, h00, h01, h02, h11, h12, h22, g0, g1, g2;
 };
@@ -177,17 +206,27 @@ __device__ __forceinline__ Normal huber_normal(const Views& vw, unsigned mask, c
         n.h11 += wgt * (jx[1] * jx[1] + jy[1] * jy[1]);
         n.h12 += wgt * (jx[1] * jx[2] + jy[1] * jy[2]);
         n.h22 += wgt * (jx[2] * jx[2] + jy[2] * jy[2]);
-        n.g0 += wgt * (jx[0] * ex + jy[0] * ey);
-        n.g1 += wgt * (jx[1] * ex + jy[1] * ey);
-        n.g2 += wgt * (jx[2] * ex + jy[2] * ey);
+        const double q0 = jx[0] * ex + jy[0] * ey, q1 = jx[1] * ex + jy[1] * ey, q2 = jx[2] * ex + jy[2] * ey;
+        n.g0 += wgt * q0;
+        n.g1 += wgt * q1;
+        n.g2 += wgt * q2;
+        if (s > 1.0) {
+            const double f = wgt / (4.0 * s);
+            n.h00 -= f * q0 * q0;
+            n.h01 -= f * q0 * q1;
+            n.h02 -= f * q0 * q2;
+            n.h11 -= f * q1 * q1;
+            n.h12 -= f * q1 * q2;
+            n.h22 -= f * q2 * q2;
+        }
     }
     return n;
 }
 
-// Damped reweighted Gauss-Newton from the DLT solution to the minimiser of the Huber cost: a step is kept only
-// if it does not raise the cost; the loop ends when the step is below 1e-10 (the unit of X; millimetres here)
-// relative to 1 + |X|, when the damping has grown past any useful step, or after kRefineSteps evaluations.
-constexpr int kRefineSteps = 200;
+// Damped Gauss-Newton from the DLT solution to the minimiser of the Huber cost: a step is kept only if it does
+// not raise the cost; the loop ends when a step, kept or not, is below 1e-10 relative to 1 + |X| (X in
+// millimetres here), when the damping has grown past any useful step, or after kRefineSteps evaluations.
+constexpr int kRefineSteps = 100;
 __device__ void huber_refine(const Views& vw, unsigned mask, double (&X)[3]) {
     Normal cur = huber_normal(vw, mask, X);
     if (!(cur.cost == cur.cost) || isinf(cur.cost)) return;
@@ -205,9 +244,9 @@ __device__ void huber_refine(const Views& vw, unsigned mask, double (&X)[3]) {
         const double d2 = (c02 * cur.g0 + c12 * cur.g1 + c22 * cur.g2) * id;
         const double cand[3] = {X[0] + d0, X[1] + d1, X[2] + d2};
         const Normal nxt = huber_normal(vw, mask, cand);
+        const double step2 = d0 * d0 + d1 * d1 + d2 * d2;
+        const double size2 = 1.0 + X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
         if (nxt.cost <= cur.cost) {  // false for NaN
-            const double step2 = d0 * d0 + d1 * d1 + d2 * d2;
-            const double size2 = 1.0 + X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
             X[0] = cand[0];
             X[1] = cand[1];
             X[2] = cand[2];
@@ -215,6 +254,7 @@ __device__ void huber_refine(const Views& vw, unsigned mask, double (&X)[3]) {
             lam = fmax(lam * 0.2, 1e-15);
             if (step2 <= 1e-20 * size2) break;
         } else {
+            if (step2 <= 1e-20 * size2) break;  // rounding noise of the cost decides at this step length
             lam *= 10.0;
             if (lam > 1e12) break;
         }
@@ -275,12 +315,22 @@ extern "C" int mvx_heatmap_argmax(const float* heatmaps, int64_t n_maps, int h, 
     const bool vec = (hw % 4 == 0) && aligned16(heatmaps);
     hipStream_t st = static_cast<hipStream_t>(stream);
     long long* out = reinterpret_cast<long long*>(keypoints);
-    if (vec)
-        hipLaunchKernelGGL(heatmap_argmax<true>, dim3(static_cast<unsigned>(n_maps)), dim3(kArgmaxThreads), 0, st,
-                           heatmaps, hw, w, scale_x, scale_y, out);
+    // A read-only stream runs fastest with about 144 KB of maps in flight per CU (4 workgroups of a 96 x 96 map);
+    // LDS the kernel does not use is requested only to cap the residency at that.
+    int per_cu = static_cast<int>((144 * 1024 + static_cast<int64_t>(hw) * 2) / (static_cast<int64_t>(hw) * 4));
+    if (per_cu < 1) per_cu = 1;
+    const size_t cap_lds = per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
+    const dim3 grid(static_cast<unsigned>(n_maps)), block(kArgmaxThreads);
+    if (vec && hw == 256 * 4 * 9)  // 96 x 96
+        hipLaunchKernelGGL(heatmap_argmax<9>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
+    else if (vec && hw == 256 * 4 * 4)  // 64 x 64
+        hipLaunchKernelGGL(heatmap_argmax<4>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
+    else if (vec && hw == 256 * 4 * 16)  // 128 x 128
+        hipLaunchKernelGGL(heatmap_argmax<16>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
+    else if (vec)
+        hipLaunchKernelGGL(heatmap_argmax<0>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
     else
-        hipLaunchKernelGGL(heatmap_argmax<false>, dim3(static_cast<unsigned>(n_maps)), dim3(kArgmaxThreads), 0, st,
-                           heatmaps, hw, w, scale_x, scale_y, out);
+        hipLaunchKernelGGL(heatmap_argmax<-1>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
     MVX_CHECK_LAUNCH("mvx_heatmap_argmax");
     return MVX_OK;
 }
