@@ -121,6 +121,17 @@ int mvx_unproject(const float* features, const float* proj, const float* coords,
                   int aggregation, float* volumes, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * mvx_unproject for feature maps that are already channel-last in memory (a torch tensor of shape
+ * [n_frames*n_views][n_channels][h][w] in torch.channels_last format, as a backbone run in that format
+ * produces): no layout copy and no workspace.  Needs n_channels % 4 == 0 and 16-byte aligned features.
+ * Same operation, same results as mvx_unproject (mvn/utils/op.py:99-166).
+ * features   [n_frames][n_views][h][w][n_channels]
+ */
+int mvx_unproject_channels_last(const float* features, const float* proj, const float* coords, const float* vol_conf,
+                                int64_t n_frames, int n_views, int n_channels, int h, int w, int vx, int vy, int vz,
+                                int aggregation, float* volumes, void* stream);
+
+/*
  * Soft-argmax over voxel grids.
  * coords_volume != NULL replaces mvn/utils/op.py:84-96 (integrate_tensor_3d_with_coordinates):
  *   softmax != 0: p = softmax over the grid; out = sum p * coord;  softmax == 0: p = max(x,0), out = sum p * coord.

@@ -31,6 +31,8 @@ SIGNATURES = {
     "mvx_unproject_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "mvx_unproject": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _sz,
                              _vp]),
+    "mvx_unproject_channels_last": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
+                                           _vp]),
     "mvx_build_coord_volumes": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _f32, _f32, _int, _vp, _vp]),
     "mvx_soft_argmax_3d_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "mvx_soft_argmax_3d": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _sz, _vp]),

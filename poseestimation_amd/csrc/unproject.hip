@@ -389,30 +389,63 @@ extern "C" size_t mvx_unproject_workspace_bytes(int64_t n_frames, int n_views, i
     return static_cast<size_t>(frames) * n_views * h * w * cp * sizeof(float);
 }
 
+namespace mvx {
+namespace {
+// channels_last: features are [n_frames][n_views][h][w][n_channels] already and no workspace is used.
+int unproject_any_layout(const char* name, bool channels_last, const float* features, const float* proj,
+                         const float* coords, const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
+                         int w, int vx, int vy, int vz, int aggregation, float* volumes, void* workspace,
+                         size_t workspace_bytes, void* stream);
+}  // namespace
+}  // namespace mvx
+
 extern "C" int mvx_unproject(const float* features, const float* proj, const float* coords, const float* vol_conf,
                              int64_t n_frames, int n_views, int n_channels, int h, int w, int vx, int vy, int vz,
                              int aggregation, float* volumes, void* workspace, size_t workspace_bytes, void* stream) {
-    using namespace mvx;
+    return mvx::unproject_any_layout("mvx_unproject", false, features, proj, coords, vol_conf, n_frames, n_views,
+                                     n_channels, h, w, vx, vy, vz, aggregation, volumes, workspace, workspace_bytes,
+                                     stream);
+}
+
+extern "C" int mvx_unproject_channels_last(const float* features, const float* proj, const float* coords,
+                                           const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
+                                           int w, int vx, int vy, int vz, int aggregation, float* volumes,
+                                           void* stream) {
+    return mvx::unproject_any_layout("mvx_unproject_channels_last", true, features, proj, coords, vol_conf, n_frames,
+                                     n_views, n_channels, h, w, vx, vy, vz, aggregation, volumes, nullptr, 0, stream);
+}
+
+namespace mvx {
+namespace {
+int unproject_any_layout(const char* name, bool channels_last, const float* features, const float* proj,
+                         const float* coords, const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
+                         int w, int vx, int vy, int vz, int aggregation, float* volumes, void* workspace,
+                         size_t workspace_bytes, void* stream) {
     MVX_REQUIRE(n_frames >= 0 && n_views > 0 && n_channels > 0 && h >= 2 && w >= 2 && vx >= 0 && vy >= 0 && vz >= 0,
-                MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: bad shape n_frames=%lld n_views=%d n_channels=%d h=%d w=%d grid=%dx%dx%d",
-                (long long)n_frames, n_views, n_channels, h, w, vx, vy, vz);
+                MVX_ERR_INVALID_ARGUMENT, "%s: bad shape n_frames=%lld n_views=%d n_channels=%d h=%d w=%d grid=%dx%dx%d",
+                name, (long long)n_frames, n_views, n_channels, h, w, vx, vy, vz);
     const int64_t n_voxels = static_cast<int64_t>(vx) * vy * vz;
     MVX_REQUIRE(aggregation >= MVX_AGG_SUM && aggregation <= MVX_AGG_SOFTMAX, MVX_ERR_INVALID_ARGUMENT,
-                "mvx_unproject: unknown aggregation %d", aggregation);
+                "%s: unknown aggregation %d", name, aggregation);
     if (n_frames == 0 || n_voxels == 0) return MVX_OK;
     MVX_REQUIRE(features != nullptr && proj != nullptr && coords != nullptr && volumes != nullptr &&
-                    workspace != nullptr,
-                MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: null pointer argument");
+                    (channels_last || workspace != nullptr),
+                MVX_ERR_INVALID_ARGUMENT, "%s: null pointer argument", name);
     MVX_REQUIRE(aggregation != MVX_AGG_CONF || vol_conf != nullptr, MVX_ERR_INVALID_ARGUMENT,
-                "mvx_unproject: confidence aggregation needs vol_conf");
-    MVX_REQUIRE(workspace_bytes >= mvx_unproject_workspace_bytes(n_frames, n_views, n_channels, h, w),
-                MVX_ERR_WORKSPACE, "mvx_unproject: workspace of %zu bytes is too small", workspace_bytes);
-    MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "mvx_unproject: workspace must be 16-byte aligned");
+                "%s: confidence aggregation needs vol_conf", name);
+    if (channels_last) {
+        MVX_REQUIRE(n_channels % 4 == 0 && aligned16(features), MVX_ERR_INVALID_ARGUMENT,
+                    "%s: channel-last features need n_channels %% 4 == 0 (got %d) and a 16-byte aligned pointer", name,
+                    n_channels);
+    } else {
+        MVX_REQUIRE(workspace_bytes >= mvx_unproject_workspace_bytes(n_frames, n_views, n_channels, h, w),
+                    MVX_ERR_WORKSPACE, "%s: workspace of %zu bytes is too small", name, workspace_bytes);
+        MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", name);
+    }
     const int C = n_channels, Cp = (C + 3) / 4 * 4, V = n_views, HW = h * w;
     MVX_REQUIRE(static_cast<int64_t>(h) * w * Cp < (1LL << 30), MVX_ERR_UNSUPPORTED,
-                "mvx_unproject: one feature map exceeds 2^30 elements (4 GB)");
+                "%s: one feature map exceeds 2^30 elements (4 GB)", name);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float* feat_cl = static_cast<float*>(workspace);
     const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
     const bool tiled = (C == 32) && (V <= kTileMaxViews) && (n_voxels % kTile == 0) && aligned16(volumes) &&
                        (aggregation != MVX_AGG_CONF || aligned16(vol_conf));
@@ -422,20 +455,27 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
     const double sx = static_cast<double>(w - 1) / static_cast<double>(h);  // ix = x / H * (W - 1)
     const double sy = static_cast<double>(h - 1) / static_cast<double>(w);  // iy = y / W * (H - 1)
 
-    for (int64_t f0 = 0; f0 < n_frames; f0 += kChunkFrames) {
-        const int64_t nf = (n_frames - f0 < kChunkFrames) ? n_frames - f0 : kChunkFrames;
-        const int64_t t_blocks = nf * V * static_cast<int64_t>(p_tiles) * c_tiles;
-        MVX_REQUIRE(t_blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: feature maps too large");
-        hipLaunchKernelGGL(to_channel_last, dim3(static_cast<unsigned>(t_blocks)), dim3(kThreads), 0, st,
-                           features + f0 * V * C * HW, C, Cp, HW, p_tiles, c_tiles, feat_cl);
-        MVX_CHECK_LAUNCH("mvx_unproject (channel-last copy)");
+    // With the layout copy, rounds of a few frames keep the copied maps in L2 for the sampling that follows;
+    // maps sampled in place have no such coupling and go in as few launches as the grid limits allow.
+    const int64_t chunk = channels_last ? 1024 : kChunkFrames;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int64_t nf = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
+        const float* feat_cl = features + f0 * V * C * HW;
+        if (!channels_last) {
+            const int64_t t_blocks = nf * V * static_cast<int64_t>(p_tiles) * c_tiles;
+            MVX_REQUIRE(t_blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: feature maps too large", name);
+            hipLaunchKernelGGL(to_channel_last, dim3(static_cast<unsigned>(t_blocks)), dim3(kThreads), 0, st,
+                               features + f0 * V * C * HW, C, Cp, HW, p_tiles, c_tiles, static_cast<float*>(workspace));
+            MVX_CHECK_LAUNCH("mvx_unproject (channel-last copy)");
+            feat_cl = static_cast<const float*>(workspace);
+        }
         const float* pj = proj + f0 * V * 12;
         const float* cd = coords + f0 * n_voxels * 3;
         const float* vc = vol_conf != nullptr ? vol_conf + f0 * V * C : nullptr;
         float* vo = volumes + f0 * C * n_voxels;
         if (tiled && !force_generic) {
             const int64_t tiles = n_voxels / kTile;
-            MVX_REQUIRE(nf * tiles <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: voxel grid too large");
+            MVX_REQUIRE(nf * tiles <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
             const dim3 grid(static_cast<unsigned>(nf * tiles));
 #define MVX_LAUNCH_TILE(AGG)                                                                                        \
     if (V == 4)                                                                                                     \
@@ -454,7 +494,7 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
         } else {
             const int64_t n_items = nf * n_voxels * (Cp / 4);
             const int64_t blocks = (n_items + kThreads - 1) / kThreads;
-            MVX_REQUIRE(blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "mvx_unproject: voxel grid too large");
+            MVX_REQUIRE(blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
             const dim3 grid(static_cast<unsigned>(blocks));
 #define MVX_LAUNCH_GENERIC(AGG)                                                                                  \
     hipLaunchKernelGGL(unproject_generic<AGG>, grid, dim3(kThreads), 0, st, feat_cl, pj, cd, vc, n_items, V, C, Cp, h, \
@@ -471,3 +511,5 @@ extern "C" int mvx_unproject(const float* features, const float* proj, const flo
     }
     return MVX_OK;
 }
+}  // namespace
+}  // namespace mvx

@@ -79,6 +79,16 @@ def integrate_tensor_3d_with_coordinates(volumes, coord_volumes, softmax=True, *
 _AGGREGATIONS = {"sum": _cabi.AGG_SUM, "max": _cabi.AGG_MAX, "softmax": _cabi.AGG_SOFTMAX}
 
 
+def _is_channels_last(t):
+    """True for a float32 HIP tensor (batch, views, c, h, w) whose memory is (batch, views, h, w, c): what
+    `.view(batch, views, c, h, w)` of a torch.channels_last (batch*views, c, h, w) tensor looks like."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 5):
+        return False
+    _, v, c, h, w = t.shape
+    return (c % 4 == 0 and t.data_ptr() % 16 == 0 and min(v, c, h, w) > 1
+            and tuple(t.stride()) == (v * h * w * c, h * w * c, 1, w * c, c))
+
+
 def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregation_method='sum', vol_confidences=None):
     """Unprojects (batch, n_views, n_joints, h, w) maps into (batch, n_joints, x, y, z) volumes;
     reference: mvn/utils/op.py:99-166.
@@ -86,7 +96,9 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
     proj_matricies (batch, n_views, 3, 4) project world points to map pixels; coord_volumes
     (batch, x, y, z, 3) hold the world position of every voxel; volume_aggregation_method is 'sum', 'max',
     'softmax' or anything starting with 'conf' (then vol_confidences (batch, n_views, n_joints) weight the
-    views).  Any other method raises ValueError, as the reference does.
+    views).  Any other method raises ValueError, as the reference does.  Maps that are channel-last in memory
+    (the output of a backbone run in torch.channels_last) are sampled in place; others are first copied to
+    that layout.
     """
     method = volume_aggregation_method
     if method.startswith('conf'):
@@ -95,7 +107,8 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
         agg = _AGGREGATIONS[method]
     else:
         raise ValueError("Unknown volume_aggregation_method: {}".format(method))
-    feats = _cabi.device_f32(heatmaps, "heatmaps")
+    channels_last = _is_channels_last(heatmaps)
+    feats = heatmaps if channels_last else _cabi.device_f32(heatmaps, "heatmaps")
     proj = _cabi.device_f32(proj_matricies, "proj_matricies")
     cv = _cabi.device_f32(coord_volumes, "coord_volumes")
     if feats.dim() != 5 or cv.dim() != 5 or cv.shape[-1] != 3:
@@ -113,6 +126,13 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
             raise ValueError("vol_confidences must have shape %s, got %s" % ((b, v, c), tuple(vc.shape)))
     volumes = torch.empty((b, c) + vshape, dtype=torch.float32, device=feats.device)
     lib = _cabi.load()
+    if channels_last:   # the maps are sampled where they lie: no layout copy, no workspace
+        with torch.cuda.device(feats.device):
+            st = lib.mvx_unproject_channels_last(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c,
+                                                 h, w, vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(volumes),
+                                                 _cabi.stream(feats.device))
+        _cabi.check(st, "mvx_unproject_channels_last")
+        return volumes
     ws_bytes = lib.mvx_unproject_workspace_bytes(b, v, c, h, w)
     ws = torch.empty((max(ws_bytes, 16) + 15) // 16 * 4, dtype=torch.float32, device=feats.device)
     with torch.cuda.device(feats.device):

@@ -259,6 +259,25 @@ def test_unproject_kernel_paths_agree(side, views, monkeypatch):
     assert torch.allclose(full[:, :, :31, :, :15], generic, rtol=0, atol=2e-6)
 
 
+def test_unproject_channels_last_input_is_sampled_in_place():
+    """Feature maps in torch.channels_last memory give the same volumes, bit for bit, without the layout copy:
+    the tile kernel (C = 32), the generic kernel (C = 8) and a C that is not a multiple of 4 (copied as usual)."""
+    for C, size in ((32, 32), (8, 12), (6, 12)):
+        case = synth.volumetric_case(23 + C, 9, 4, volume_size=size, with_volumes=False)
+        feats = to_dev(case["features"])[:, :, :C].contiguous()
+        proj, coord, vconf = to_dev(case["proj"]), to_dev(case["coord_volumes"]), to_dev(case["vol_confidences"])[:, :, :C].contiguous()
+        B, V, _, h, w = feats.shape
+        cl = feats.view(B * V, C, h, w).contiguous(memory_format=torch.channels_last).view(B, V, C, h, w)
+        assert op._is_channels_last(cl) == (C % 4 == 0) and not op._is_channels_last(feats)
+        for method in ("softmax", "conf", "sum", "max"):
+            assert torch.equal(op.unproject_heatmaps(cl, proj, coord, method, vconf),
+                               op.unproject_heatmaps(feats, proj, coord, method, vconf))
+    lib = _cabi.load()
+    st = lib.mvx_unproject_channels_last(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(coord), None, 9, 4, 6, 96, 96,
+                                         12, 12, 12, _cabi.AGG_SUM, _cabi.ptr(coord), _cabi.stream(dev()))
+    assert st == _cabi.MVX_ERR_INVALID_ARGUMENT and b"n_channels % 4" in lib.mvx_last_error()
+
+
 def test_unproject_sum_is_linear_at_batch_size():
     """Size-independent property at a larger batch: 'sum' aggregation is linear in the features."""
     case = synth.volumetric_case(22, 9, 4, volume_size=32, with_volumes=False)

@@ -85,6 +85,28 @@ def test_heatmap_argmax_unaligned_view():
     assert np.array_equal(keypoints.cpu().numpy(), orc.heatmap_argmax_keypoints(hm.cpu().numpy(), (32, 32)))
 
 
+def test_heatmap_argmax_full_batch_planted_maxima():
+    """At the benchmark's size (4096 x 4 x 17 = 278 528 maps, 10.3 GB): a maximum planted at a known, different
+    place in every map is found, and the RANSAC points of the whole batch equal those of the same frames
+    triangulated in slices."""
+    case = synth.device_algebraic_case(1236, 4096, 4, dev())
+    hm = case["heatmaps"]
+    B, V, J, h, w = hm.shape
+    n = B * V * J
+    where = (torch.arange(n, device=dev(), dtype=torch.int64) * 7919) % (h * w)
+    hm.view(n, -1).scatter_(1, where[:, None], 1.0e4)
+    net = _ransac_net(view_pairs="all")
+    kp = net.keypoints_from_heatmaps(hm, (384, 384))
+    assert torch.equal(kp.view(n, 2)[:, 0], (where % w) * 4) and torch.equal(kp.view(n, 2)[:, 1], (where // w) * 4)
+    # triangulation: whole batch against slices of it (planted keypoints are far from consistent: most pair
+    # hypotheses find no further inlier, and the first largest set must be the same either way)
+    pairs = tri.all_view_pairs(B * J, V)
+    whole, masks = tri.ransac_triangulate_batch(case["proj"], kp, pairs, 15, True)
+    for lo in (0, 1777, 4000):
+        part, pm = tri.ransac_triangulate_batch(case["proj"][lo:lo + 96], kp[lo:lo + 96], pairs[:96 * J], 15, True)
+        assert torch.equal(part, whole[lo:lo + 96]) and torch.equal(pm, masks[lo:lo + 96])
+
+
 # ---- RANSAC ----------------------------------------------------------------------------------------------------
 def test_ransac_points_match_reference():
     g = load("ransac")

@@ -79,6 +79,11 @@ def k3(rounds):
     for method in ("softmax", "conf", "sum", "max"):
         print("--", method)
         time_variants(lambda: (op.unproject_heatmaps(f, p, c, method, vc),), "MVX_UNPROJ_PATH", ["tile", "generic"], rounds, inner=2)
+    B, V, C, h, w = f.shape
+    fcl = f.view(B * V, C, h, w).contiguous(memory_format=torch.channels_last).view(B, V, C, h, w)
+    print("-- softmax, channel-last input")
+    time_variants(lambda: (op.unproject_heatmaps(fcl, p, c, "softmax", vc),), "MVX_UNPROJ_PATH", ["tile"], rounds, inner=2)
+
 
 
 def k4(rounds):

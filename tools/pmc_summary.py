@@ -13,7 +13,7 @@ for f in sorted(glob.glob(root + "/pass*/*/*counter_collection.csv")):
         name = row["Kernel_Name"]
         if flt not in name:
             continue
-        short = name.split("(")[0].replace("void mvx::", "").replace("(anonymous namespace)::", "")[:60]
+        short = name.replace("(anonymous namespace)::", "").replace("void mvx::", "").replace("mvx::", "").split("(")[0][:60]
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
     print("==", k)
