@@ -1,0 +1,23 @@
+#!/bin/bash
+# Development tool (runs on the GPU box): the bench lines and rocprofv3 kernel summaries kept under profiles/.
+#   tools/measure_all.sh <out-dir-under-gpurun_out>
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$1
+mkdir -p "$OUT"
+cd "$R" || exit 1
+run() {  # name, args...
+  local name=$1; shift
+  timeout -k 10 280 python3 -u bench.py "$@" > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || { echo "bench $name failed"; tail -5 "$OUT/bench_$name.err"; exit 1; }
+  echo "bench $name ok"
+}
+run algebraic
+run algebraic_coords_only --no-writeback --no-cpu-baseline
+run volumetric --workload volumetric
+run stream16 --workload stream16
+run ransac --workload ransac
+cd /tmp && export TMPDIR=/tmp
+for W in algebraic volumetric ransac; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$W" -- python3 "$R/bench.py" --workload $W --steps 10 --no-cpu-baseline > "$OUT/prof_$W.log" 2>&1 || { echo "rocprof $W failed"; tail -5 "$OUT/prof_$W.log"; exit 1; }
+  echo "rocprof $W ok"
+done
