@@ -3,12 +3,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload algebraic|volumetric|stream16|ransac]
 
 A step is one pass of the path over one resident batch of synthetic frames:
-  algebraic  (default; BASELINE.json configs[1]) 4096 frames x 4 views x 17 joints of 96x96 heatmaps per GPU:
+  algebraic  (default: the headline configuration) 4096 frames x 4 views x 17 joints of 96x96 heatmaps per GPU:
              soft-argmax (multiplier folded in, normalised heatmaps written back as the reference returns them)
              -> confidence normalisation + keypoint upscale + DLT.
-  volumetric (configs[2]) 64 frames: 4 views x 32-channel 96x96 features unprojected into 64^3 (softmax
+  volumetric 64 frames: 4 views x 32-channel 96x96 features unprojected into 64^3 (softmax
              aggregation), 17 volumes per frame soft-argmaxed with coordinates (normalised volumes written).
-  stream16   (configs[4]) 16 views: p50 latency of one frame and throughput at 1024 frames.
+  stream16   16 views: p50 latency of one frame and throughput at 1024 frames.
   ransac     the reference's third triangulation model on the algebraic shapes: arg-max keypoints of 4096 x 4 x 17
              heatmaps, then RANSAC over every view pair + DLT over the inliers + Huber refinement per joint.
 With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds its own batch (weak scaling,

@@ -1,5 +1,5 @@
-// Eigenvector of the smallest eigenvalue of a symmetric 4 x 4 matrix by cyclic Jacobi rotations, all in
-// registers with compile-time indices.  Shared by the DLT and RANSAC triangulation kernels, where the matrix is
+// Eigenvector of the smallest eigenvalue of a symmetric 4 x 4 matrix by cyclic Jacobi rotations (round-robin
+// order: the three pairs of disjoint planes), all in registers with compile-time indices.  Shared by the DLT and RANSAC triangulation kernels, where the matrix is
 // the Gram matrix A^T A of a DLT design matrix and the eigenvector is the right singular vector of A's smallest
 // singular value.
 #pragma once
@@ -12,7 +12,7 @@ constexpr int kMaxJacobiSweeps = 16;
 
 // 1/x and 1/sqrt(x) to float64 accuracy from the hardware estimates (v_rcp_f64 / v_rsq_f64, about 2^-26 relative
 // error, refined by two Newton steps each): a much shorter dependent chain than the IEEE division and square
-// root routines, which matters because one lane walks 6 rotations x several sweeps serially.
+// root routines, which matters because one lane walks 3 rotation pairs x several sweeps serially.
 __device__ __forceinline__ double rcp_refined(double x) {
     double y = __builtin_amdgcn_rcp(x);
     y = fma(y, fma(-x, y, 1.0), y);
@@ -26,36 +26,45 @@ __device__ __forceinline__ double rsqrt_refined(double x) {
     return y;
 }
 
-// One Jacobi rotation annihilating a[P][Q] (P < Q); a is kept full and symmetric, v accumulates the
-// rotations (columns of v are the eigenvectors).  t = tan(angle) is the smaller root of t^2 + 2 t theta - 1 = 0,
-// theta = (a_qq - a_pp) / (2 a_pq); for |theta| beyond 1e100 the square would overflow and t = 1 / (2 theta).
-template <int P, int Q>
-__device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][4]) {
-    const double apq = a[P][Q];
-    if (apq == 0.0) return;
-    const double theta = (a[Q][Q] - a[P][P]) * 0.5 * rcp_refined(apq);
+// Parameters of the Jacobi rotation that annihilates a_pq: t = tan(angle) is the smaller root of
+// t^2 + 2 t theta - 1 = 0, theta = (a_qq - a_pp) / (2 a_pq); for |theta| beyond 1e100 the square would overflow
+// and t = 1 / (2 theta) (also the limit for theta = inf).  Branch-free, so that the chains of two independent
+// rotations interleave: a_pq == 0 or a NaN gives the identity (t = 0, c = 1, s = 0).
+struct Rotation {
+    double t, c, s;
+    bool on;
+};
+__device__ __forceinline__ Rotation rotation_for(double app, double aqq, double apq) {
+    const double theta = (aqq - app) * 0.5 * rcp_refined(apq);
     const double ath = fabs(theta);
-    double t;
-    if (ath < 1e100) {
-        const double x = fma(theta, theta, 1.0);
-        t = rcp_refined(ath + x * rsqrt_refined(x));
-    } else {
-        t = 0.5 * rcp_refined(ath);  // also the limit for theta = inf (t = 0); NaN falls through to the check below
-    }
+    const double x = fma(theta, theta, 1.0);
+    const double t_small = rcp_refined(ath + x * rsqrt_refined(x));
+    const double t_large = 0.5 * rcp_refined(ath);
+    double t = ath < 1e100 ? t_small : t_large;
     t = theta >= 0.0 ? t : -t;
-    if (!(t == t)) return;
-    const double c = rsqrt_refined(fma(t, t, 1.0));
-    const double s = t * c;
-    a[P][P] = fma(-t, apq, a[P][P]);
-    a[Q][Q] = fma(t, apq, a[Q][Q]);
-    a[P][Q] = 0.0;
-    a[Q][P] = 0.0;
+    Rotation r;
+    r.on = (apq != 0.0) && (t == t);
+    r.t = r.on ? t : 0.0;
+    r.c = rsqrt_refined(fma(r.t, r.t, 1.0));
+    r.s = r.t * r.c;
+    return r;
+}
+
+// Applies the rotation in the (P, Q) plane; a is kept full and symmetric, v accumulates the rotations (columns
+// of v are the eigenvectors).
+template <int P, int Q>
+__device__ __forceinline__ void apply_rotation(const Rotation& r, double (&a)[4][4], double (&v)[4][4]) {
+    const double apq = a[P][Q];
+    a[P][P] = fma(-r.t, apq, a[P][P]);
+    a[Q][Q] = fma(r.t, apq, a[Q][Q]);
+    a[P][Q] = r.on ? 0.0 : apq;
+    a[Q][P] = a[P][Q];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k != P && k != Q) {
             const double akp = a[k][P], akq = a[k][Q];
-            const double np_ = c * akp - s * akq;
-            const double nq_ = s * akp + c * akq;
+            const double np_ = r.c * akp - r.s * akq;
+            const double nq_ = r.s * akp + r.c * akq;
             a[k][P] = np_;
             a[P][k] = np_;
             a[k][Q] = nq_;
@@ -65,9 +74,20 @@ __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const double vkp = v[k][P], vkq = v[k][Q];
-        v[k][P] = c * vkp - s * vkq;
-        v[k][Q] = s * vkp + c * vkq;
+        v[k][P] = r.c * vkp - r.s * vkq;
+        v[k][Q] = r.s * vkp + r.c * vkq;
     }
+}
+
+// Two rotations in disjoint planes.  The first does not touch a_rr, a_ss or a_rs, so both parameter sets come
+// from the same matrix and their (long, dependent) evaluations overlap; applying them one after the other is
+// then exactly the sequential Jacobi step.
+template <int P, int Q, int R, int S>
+__device__ __forceinline__ void jacobi_pair(double (&a)[4][4], double (&v)[4][4]) {
+    const Rotation r1 = rotation_for(a[P][P], a[Q][Q], a[P][Q]);
+    const Rotation r2 = rotation_for(a[R][R], a[S][S], a[R][S]);
+    apply_rotation<P, Q>(r1, a, v);
+    apply_rotation<R, S>(r2, a, v);
 }
 
 __device__ __forceinline__ bool off_diagonal_negligible(const double (&a)[4][4]) {
@@ -89,12 +109,9 @@ __device__ __forceinline__ void smallest_eigenvector(double (&g)[4][4], double (
         for (int q = 0; q < 4; ++q) e[p][q] = (p == q) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < kMaxJacobiSweeps; ++sweep) {
         if (off_diagonal_negligible(g)) break;
-        jacobi_rotate<0, 1>(g, e);
-        jacobi_rotate<0, 2>(g, e);
-        jacobi_rotate<0, 3>(g, e);
-        jacobi_rotate<1, 2>(g, e);
-        jacobi_rotate<1, 3>(g, e);
-        jacobi_rotate<2, 3>(g, e);
+        jacobi_pair<0, 1, 2, 3>(g, e);
+        jacobi_pair<0, 2, 1, 3>(g, e);
+        jacobi_pair<0, 3, 1, 2>(g, e);
     }
     double best = g[0][0];
 #pragma unroll

@@ -194,14 +194,18 @@ class AlgebraicTriangulationNet(nn.Module):
         # one allocation for the small outputs: heatmap-pixel keypoints, image-pixel keypoints, confidences, joints
         n2, n1, n3 = b * v * j * 2, b * v * j, b * j * 3
         small = torch.empty(2 * n2 + n1 + n3, dtype=torch.float32, device=hm.device)
-        kp_hm, kp_img = small[:n2], small[n2:2 * n2].view(b, v, j, 2)
-        conf_norm, kp3d = small[2 * n2:2 * n2 + n1].view(b, v, j), small[2 * n2 + n1:].view(b, j, 3)
-        with torch.cuda.device(hm.device):
-            st = _cabi.load().mvx_algebraic_forward(
-                _cabi.ptr(hm), _cabi.ptr(conf), _cabi.ptr(proj), b, v, j, h, w, float(self.heatmap_multiplier),
+        _, kp_img, conf_norm, kp3d = small.split((n2, n2, n1, n3))
+        kp_img, conf_norm, kp3d = kp_img.view(b, v, j, 2), conf_norm.view(b, v, j), kp3d.view(b, j, 3)
+        base = small.data_ptr()
+        args = (_cabi.ptr(hm), _cabi.ptr(conf), _cabi.ptr(proj), b, v, j, h, w, float(self.heatmap_multiplier),
                 int(bool(self.heatmap_softmax)), float(image_shape[1] / w), float(image_shape[0] / h),
-                _cabi.ptr(hm_norm), _cabi.ptr(kp_img), _cabi.ptr(conf_norm), _cabi.ptr(kp3d), _cabi.ptr(kp_hm),
-                _cabi.stream(hm.device))
+                _cabi.ptr(hm_norm), base + 4 * n2, base + 8 * n2, base + 8 * n2 + 4 * n1, base)
+        lib = _cabi.load()
+        if hm.device.index == torch.cuda.current_device():   # the common case: no device switch around the call
+            st = lib.mvx_algebraic_forward(*args, _cabi.stream(hm.device))
+        else:
+            with torch.cuda.device(hm.device):
+                st = lib.mvx_algebraic_forward(*args, _cabi.stream(hm.device))
         _cabi.check(st, "mvx_algebraic_forward")
         return kp3d, kp_img, hm_norm, conf_norm
 

@@ -57,6 +57,26 @@ for V in (4, 16):
         torch.cuda.synchronize()
         return a.elapsed_time(e) * 1e3 / n
 
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        st_side = _cabi.stream(dev)
+
+        def raw_side():
+            lib.mvx_soft_argmax_2d(_cabi.ptr(hm), b * v * j, h, w, 100.0, 1, _cabi.ptr(kp_hm), _cabi.ptr(hm_out), st_side)
+            lib.mvx_algebraic_glue_dlt(_cabi.ptr(proj), _cabi.ptr(kp_hm), _cabi.ptr(conf), b, v, j, 4.0, 4.0,
+                                       _cabi.ptr(kp_img), _cabi.ptr(conf_n), _cabi.ptr(kp3d), st_side)
+        raw_side()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            raw_side()
+    torch.cuda.synchronize()
+    before = kp3d.clone()
+    kp3d.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(before, kp3d)
+    print("V=%d graph replay: p50 %.1f us p99 %.1f us, back-to-back %.1f us" % ((V,) + p50(graph.replay) + (gpu_only(graph.replay),)))
     print("V=%d raw C calls: p50 %.1f us p99 %.1f us | wrapper: p50 %.1f us p99 %.1f us | back-to-back raw %.1f us, wrapper %.1f us per frame"
           % ((V,) + p50(raw) + p50(wrapped) + (gpu_only(raw), gpu_only(wrapped))))
     t0 = time.perf_counter()
