@@ -13,7 +13,9 @@ __version__ = "0.1.0"
 def patch_reference():
     """Replaces the triangulation functions of an importable reference `mvn` package (its checkout on
     sys.path) with the HIP-backed ones, so that the reference's own model classes and pipelines call the
-    kernels unchanged.  Returns the list of patched attribute names."""
+    kernels unchanged.  The RANSAC model class, the `prepare_batch*` functions and the temporal filter are
+    swapped as well when their reference modules import (they pull in optional dependencies such as OpenCV).
+    Returns the list of patched attribute names."""
     import importlib
 
     from poseestimation_amd.mvn.utils import multiview as mv, op as ops
@@ -28,4 +30,20 @@ def patch_reference():
     for name in ("triangulate_batch_of_points", "triangulate_point_from_multiple_views_linear_torch"):
         setattr(ref_mv, name, getattr(mv, name))
         patched.append("mvn.utils.multiview." + name)
+
+    optional = (
+        ("mvn.models.triangulation", "poseestimation_amd.mvn.models.triangulation", ("RANSACTriangulationNet",)),
+        ("mvn.datasets.utils", "poseestimation_amd.mvn.datasets.utils",
+         ("prepare_batch", "prepare_batch_test", "prepare_batch_video")),
+        ("savgol_filer", "poseestimation_amd.savgol_filer", ("SAVGOLFilter",)),
+    )
+    for ref_name, own_name, names in optional:
+        try:
+            ref_mod = importlib.import_module(ref_name)
+        except ImportError:
+            continue
+        own_mod = importlib.import_module(own_name)
+        for name in names:
+            setattr(ref_mod, name, getattr(own_mod, name))
+            patched.append(ref_name + "." + name)
     return patched

@@ -178,3 +178,53 @@ def test_heatmap_projections_match_the_camera_loop():
             cam.update_after_resize((384, 320), (96, 80))
             np.testing.assert_allclose(P[b, v], cam.projection, rtol=1e-15, atol=1e-12)
             assert np.array_equal(cams[v][b].K, K[b, v])
+
+
+def test_patch_reference_swaps_functions_in_a_reference_like_package(tmp_path, monkeypatch):
+    """patch_reference() against a stand-in package with the reference's module layout (the reference itself is
+    not needed, and is not on the GPU box)."""
+    import importlib
+    import sys
+    import textwrap
+
+    import poseestimation_amd
+    from poseestimation_amd.mvn.utils import multiview as mv, op as ops
+
+    root = tmp_path / "fake_reference"
+    for d in ("mvn", "mvn/utils", "mvn/datasets", "mvn/models"):
+        (root / d).mkdir(parents=True)
+        (root / d / "__init__.py").write_text("")
+    (root / "mvn/utils/op.py").write_text(textwrap.dedent("""
+        def integrate_tensor_2d(*a, **k): return "reference"
+        def integrate_tensor_3d(*a, **k): return "reference"
+        def integrate_tensor_3d_with_coordinates(*a, **k): return "reference"
+        def unproject_heatmaps(*a, **k): return "reference"
+        def untouched(): return "reference"
+    """))
+    (root / "mvn/utils/multiview.py").write_text(textwrap.dedent("""
+        def triangulate_batch_of_points(*a, **k): return "reference"
+        def triangulate_point_from_multiple_views_linear_torch(*a, **k): return "reference"
+    """))
+    (root / "mvn/datasets/utils.py").write_text("def prepare_batch(*a): return 'reference'\n"
+                                               "def prepare_batch_test(*a): return 'reference'\n"
+                                               "def prepare_batch_video(*a): return 'reference'\n")
+    (root / "mvn/models/triangulation.py").write_text("import module_that_does_not_exist\n")
+    (root / "savgol_filer.py").write_text("class SAVGOLFilter: pass\n")
+    monkeypatch.syspath_prepend(str(root))
+    for name in [m for m in sys.modules if m == "mvn" or m.startswith("mvn.") or m == "savgol_filer"]:
+        monkeypatch.delitem(sys.modules, name)
+    try:
+        patched = poseestimation_amd.patch_reference()
+        ref_op = importlib.import_module("mvn.utils.op")
+        assert ref_op.unproject_heatmaps is ops.unproject_heatmaps and ref_op.untouched() == "reference"
+        assert importlib.import_module("mvn.utils.multiview").triangulate_batch_of_points is mv.triangulate_batch_of_points
+        from poseestimation_amd.mvn.datasets import utils as own_data
+        from poseestimation_amd.savgol_filer import SAVGOLFilter
+        assert importlib.import_module("mvn.datasets.utils").prepare_batch is own_data.prepare_batch
+        assert importlib.import_module("savgol_filer").SAVGOLFilter is SAVGOLFilter
+        assert "mvn.utils.op.integrate_tensor_2d" in patched and "savgol_filer.SAVGOLFilter" in patched
+        # a reference module that does not import (missing optional dependency) is skipped, not fatal
+        assert not any(p.startswith("mvn.models.triangulation") for p in patched)
+    finally:
+        for name in [m for m in sys.modules if m == "mvn" or m.startswith("mvn.") or m == "savgol_filer"]:
+            sys.modules.pop(name, None)
