@@ -71,5 +71,27 @@ int main() {
         printf("%-14s %7.0f\n", ent.name, 2.0 * bytes / (ms[ms.size() / 2] * 1e-3) / 1e9);
         fflush(stdout);
     }
+    // the same copy (nt loads, nt stores) with the destination shifted against the source: do the read and the
+    // write stream collide in the DRAM banks when both buffers start on the same alignment?
+    printf("dst shift (bytes)  GB/s\n");
+    const size_t shifts[] = {0, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20, (1 << 20) + 4096, 3 << 20, 16 << 20};
+    vec4f* dst2;
+    CHECK(hipMalloc(&dst2, bytes + (32 << 20)));
+    CHECK(hipFuncSetAttribute((const void*)k_nt_nt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap_lds));
+    for (size_t sh : shifts) {
+        std::vector<float> ms;
+        vec4f* d = reinterpret_cast<vec4f*>(reinterpret_cast<char*>(dst2) + sh);
+        for (int r = 0; r < 9; ++r) {
+            CHECK(hipEventRecord(a));
+            hipLaunchKernelGGL(k_nt_nt, dim3((unsigned)n_tiles), dim3(256), cap_lds, 0, src, d);
+            CHECK(hipEventRecord(b));
+            CHECK(hipEventSynchronize(b));
+            float t;
+            CHECK(hipEventElapsedTime(&t, a, b));
+            if (r >= 2) ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("%-18zu %7.0f   (src %p dst %p)\n", sh, 2.0 * bytes / (ms[ms.size() / 2] * 1e-3) / 1e9, (void*)src, (void*)d);
+    }
     return 0;
 }
