@@ -190,7 +190,11 @@ def run_volumetric(args, dev, rank, world, frames=64):
             "achieved": b3 / (k3.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": b3, "avg_launch_ms": k3.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    extra = {"soft_argmax_3d_ms": k4.mean_ms(), "soft_argmax_3d_GBps": b4 / (k4.mean_ms() * 1e-3) / 1e9}
+    # the unprojection gathers 4 taps x 32 channels x 4 B per voxel and view through the vector L1; a CU returns
+    # 46 B/clk for loads of that shape when everything hits (tools/l1_bandwidth.hip: 28.2 TB/s over the chip)
+    tap_bytes = frames * n_vox * 4 * 512
+    extra = {"soft_argmax_3d_ms": k4.mean_ms(), "soft_argmax_3d_GBps": b4 / (k4.mean_ms() * 1e-3) / 1e9,
+             "unproject_tap_TBps": tap_bytes / (k3.mean_ms() * 1e-3) / 1e12, "measured_l1_gather_ceiling_TBps": 28.2}
     cfg = {"workload": "volumetric: unproject 4 views x 32ch 96x96 -> 64^3 (softmax) + 3-D soft-argmax of 17 volumes, %d frames/GPU"
                        % frames, "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world}
     return ms, frames, roof, cfg, extra
