@@ -214,6 +214,44 @@ def test_ransac_batch_size_and_degenerate_pairs():
     assert np.abs(pts2.cpu().numpy() - full).max() < 1e-6
 
 
+def test_ransac_edge_cases():
+    """Two views (the minimum), no hypotheses at all, a threshold nothing passes, and non-finite input: every
+    lane terminates and the results follow the restatement."""
+    case = synth.algebraic_case(1292, 2, 2)
+    proj = case["proj"]
+    kp = orc.heatmap_argmax_keypoints(case["heatmaps"], (384, 384))
+    J = kp.shape[2]
+    pairs = tri.all_view_pairs(2 * J, 2)
+    pts, masks = tri.ransac_triangulate_batch(to_dev(proj), to_dev(kp), pairs, 15, True)
+    ref, ref_masks = orc.ransac_batch(proj, kp, pairs, 15, False)
+    assert (masks.cpu().numpy() == 3).all() and np.array_equal(ref_masks, masks.cpu().numpy())
+    # two views: the refinement starts at the DLT point and may only lower the Huber cost
+    for b in range(2):
+        for j in range(J):
+            assert orc.huber_cost(pts[b, j].cpu().numpy(), kp[b, :, j], proj[b]) <= \
+                orc.huber_cost(ref[b, j], kp[b, :, j], proj[b]) * (1 + 1e-12) + 1e-14
+    case4 = synth.algebraic_case(1293, 1, 4)
+    kp4 = orc.heatmap_argmax_keypoints(case4["heatmaps"], (384, 384))
+    none = np.zeros((J, 0, 2), dtype=np.uint8)
+    pts0, masks0 = tri.ransac_triangulate_batch(to_dev(case4["proj"]), to_dev(kp4), none, 15, False)
+    ref0, _ = orc.ransac_batch(case4["proj"], kp4, none, 15, False)
+    assert (masks0.cpu().numpy() == 15).all() and np.abs(pts0.cpu().numpy() - ref0).max() < 1e-6
+    # epsilon = 0: no view passes, the first pair is the inlier set
+    pairs4 = tri.all_view_pairs(J, 4)
+    _, masks_e = tri.ransac_triangulate_batch(to_dev(case4["proj"]), to_dev(kp4), pairs4, 0.0, False)
+    assert (masks_e.cpu().numpy() == 3).all()
+    bad = kp4.astype(np.float64)
+    bad[0, 1, 5] = np.nan
+    bad[0, 2, 6] = np.inf
+    pts_bad, _ = tri.ransac_triangulate_batch(to_dev(case4["proj"]), to_dev(bad), pairs4, 15, True)
+    torch.cuda.synchronize()
+    good = np.ones(J, dtype=bool)
+    good[[5, 6]] = False
+    ref_good, _ = orc.ransac_batch(case4["proj"], kp4, pairs4, 15, False)
+    assert np.isfinite(pts_bad.cpu().numpy()[0, good]).all()
+    assert np.abs(pts_bad.cpu().numpy()[0, good] - ref_good[0, good]).max() < 50.0   # refined vs unrefined
+
+
 def test_ransac_argument_errors():
     proj = torch.zeros(1, 4, 3, 4, device=dev())
     kp = torch.zeros(1, 4, 17, 2, dtype=torch.int64, device=dev())
