@@ -264,6 +264,7 @@ def run_ransac(args, dev, rank, world, frames=4096):
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": ka.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"], roof["traffic_source"] = measured_traffic("heatmap_argmax<9>", frames, v, False)
     extra = {"ransac_kernel_and_casts_ms": kr.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err),
              "mean_inlier_views": float(torch.bitwise_and(masks.view(-1, 1) >> torch.arange(4, device=dev), 1).sum(1).float().mean())}
     cfg = {"workload": "ransac: heatmap arg-max + RANSAC (all 6 view pairs) + inlier DLT + Huber refinement, "

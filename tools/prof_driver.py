@@ -24,6 +24,12 @@ if which == "k1":
     hm = torch.empty((frames * 4, 17, 96, 96), device=dev).normal_(generator=g)
     for _ in range(n):
         op.integrate_tensor_2d(hm, True, multiplier=100.0)
+elif which == "argmax":
+    frames = int(os.environ.get("FRAMES", "4096"))
+    hm = torch.empty((frames, 4, 17, 96, 96), device=dev).normal_(generator=g)
+    kp = torch.empty((frames, 4, 17, 2), dtype=torch.int64, device=dev)
+    for _ in range(n):
+        _cabi.load().mvx_heatmap_argmax(_cabi.ptr(hm), frames * 4 * 17, 96, 96, 4.0, 4.0, _cabi.ptr(kp), _cabi.stream(dev))
 elif which == "k2":
     P = torch.empty((4096, 4, 3, 4), device=dev).normal_(generator=g)
     P[..., 2, 3] += 4000.0
