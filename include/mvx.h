@@ -225,6 +225,15 @@ int mvx_unity_points(const float* points, const int32_t* joint_order, int64_t n_
 int mvx_realtime_tail(const float* frames, int n_steps, int n_joints, const double* hat, int window,
                       const int32_t* joint_order, float scale, float* out, void* stream);
 
+/*
+ * HOST function (no device work): fills view_pairs with the sorted pairs that n_draws successive calls of
+ * Python's random.sample(range(n_views), 2) return, reading and advancing the Mersenne Twister state of Python's
+ * `random` module (random.getstate()[1]: 624 words and the position).  This is how RANSACTriangulationNet draws its
+ * hypotheses, mvn/models/triangulation.py:96-97; doing it here avoids one interpreter call per draw.
+ * mt_state    [624] in/out      mt_pos  in/out (0..624)      view_pairs  [n_draws][2], first < second
+ */
+int mvx_draw_view_pairs(uint32_t* mt_state, int32_t* mt_pos, int n_views, int64_t n_draws, uint8_t* view_pairs);
+
 #ifdef __cplusplus
 }
 #endif

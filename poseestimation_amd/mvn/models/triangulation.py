@@ -46,12 +46,9 @@ def _sync(device):
         torch.cuda.synchronize(device)
 
 
-def draw_view_pairs(n_points, n_views, n_iters):
-    """(n_points, n_iters, 2) uint8 view pairs drawn exactly as the reference draws them: for each point in
-    order, `n_iters` calls of `sorted(random.sample(views, 2))` on Python's global generator
-    (mvn/models/triangulation.py:96-97), so that `random.seed(s)` before a forward gives the reference's
-    hypotheses.  (The reference samples from a set, which Python 3.11 no longer accepts; a range of the same
-    length consumes the generator identically.)"""
+def draw_view_pairs_python(n_points, n_views, n_iters):
+    """The draws of `draw_view_pairs` through the interpreter, one `random.sample` call each (the check for the
+    native routine)."""
     views = range(n_views)
     sample = random.sample
     pairs = np.empty((n_points, n_iters, 2), dtype=np.uint8)
@@ -59,6 +56,28 @@ def draw_view_pairs(n_points, n_views, n_iters):
         for i in range(n_iters):
             a, b = sample(views, 2)
             pairs[p, i, 0], pairs[p, i, 1] = (a, b) if a < b else (b, a)
+    return pairs
+
+
+def draw_view_pairs(n_points, n_views, n_iters):
+    """(n_points, n_iters, 2) uint8 view pairs drawn exactly as the reference draws them: for each point in
+    order, `n_iters` calls of `sorted(random.sample(views, 2))` on Python's global generator
+    (mvn/models/triangulation.py:96-97), so that `random.seed(s)` before a forward gives the reference's
+    hypotheses.  (The reference samples from a set, which Python 3.11 no longer accepts; a range of the same
+    length consumes the generator identically.)  The draws are made by a native host routine that continues
+    the generator's Mersenne Twister state and hands it back, so Python's `random` ends up where the
+    reference's calls would have left it."""
+    if not 2 <= n_views <= 255:
+        raise ValueError("view pairs are stored as uint8: 2 to 255 views, got %d" % n_views)
+    import ctypes
+    version, internal, gauss_next = random.getstate()
+    state = np.array(internal[:624], dtype=np.uint32)
+    pos = ctypes.c_int32(internal[624])
+    pairs = np.empty((n_points, n_iters, 2), dtype=np.uint8)
+    st = _cabi.load().mvx_draw_view_pairs(state.ctypes.data, ctypes.addressof(pos), int(n_views),
+                                          int(n_points) * int(n_iters), pairs.ctypes.data)
+    _cabi.check(st, "mvx_draw_view_pairs")
+    random.setstate((version, tuple(int(x) for x in state) + (pos.value,), gauss_next))
     return pairs
 
 

@@ -12,7 +12,7 @@ import golden_cases as gc
 import mvn_oracle as orc
 from poseestimation_amd import _cabi
 from poseestimation_amd.mvn.datasets import utils as data_utils
-from poseestimation_amd.mvn.models.triangulation import all_view_pairs, draw_view_pairs
+from poseestimation_amd.mvn.models.triangulation import all_view_pairs, draw_view_pairs, draw_view_pairs_python
 from poseestimation_amd.mvn.utils import multiview
 from poseestimation_amd.savgol_filer import fit_window
 
@@ -72,6 +72,26 @@ def test_draw_view_pairs_follows_python_random():
     assert pairs.dtype == np.uint8 and pairs.tolist() == expect
     every = all_view_pairs(3, 4)
     assert every.shape == (3, 6, 2) and every[1].tolist() == [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]
+
+
+@pytest.mark.parametrize("n_views", [2, 3, 4, 5, 8, 16, 21, 22, 23, 32, 64, 255])
+def test_native_view_pair_draws_continue_pythons_generator(n_views):
+    """The native host routine against random.sample itself: same pairs (both of CPython's sampling paths, at
+    and below 21 views and above), and Python's generator is left exactly where the interpreter calls leave it."""
+    for seed in (0, 7, 12345):
+        random.seed(seed)
+        burn = [random.random() for _ in range(seed % 650)]      # start at different positions of the state block
+        want = draw_view_pairs_python(200, n_views, 10)
+        after_want = (random.random(), random.getstate())
+        random.seed(seed)
+        assert burn == [random.random() for _ in range(seed % 650)]
+        got = draw_view_pairs(200, n_views, 10)
+        assert got.dtype == np.uint8
+        assert np.array_equal(got, want)
+        assert (random.random(), random.getstate()) == after_want
+    assert (draw_view_pairs(0, n_views, 10).shape, draw_view_pairs(3, n_views, 0).shape) == ((0, 10, 2), (3, 0, 2))
+    with pytest.raises(ValueError):
+        draw_view_pairs(1, 256, 1)
 
 
 # ---- temporal filter ---------------------------------------------------------------------------------------------
@@ -152,3 +172,4 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     assert lib.mvx_savgol_filter(None, 0, 51, None, 7, None, None) == _cabi.MVX_OK
     assert lib.mvx_realtime_tail(None, 1, 17, None, 1, None, 1.0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
     assert lib.mvx_unity_points(None, None, -1, 17, 1.0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_draw_view_pairs(None, None, 4, 10, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
