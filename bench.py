@@ -12,7 +12,8 @@ A step is one pass of the path over one resident batch of synthetic frames:
   ransac     the reference's third triangulation model on the algebraic shapes: arg-max keypoints of 4096 x 4 x 17
              heatmaps, then RANSAC over every view pair + DLT over the inliers + Huber refinement per joint.
 With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds its own batch (weak scaling,
-frames sharded across ranks) and each step ends with the RCCL all-gather of the (frames, 17, 3) keypoints.
+frames sharded across ranks) and each step ends with the RCCL all-gather of the (frames, 17, 3) keypoints, which
+runs on RCCL's stream while the next step computes; every all-gather has completed before the clock stops.
 Rank 0 prints one JSON line; `value` is the whole-job frames/s with inputs resident in HBM.
 """
 import argparse
@@ -117,11 +118,12 @@ def run_algebraic(args, dev, rank, world, n_views=4, frames=4096, writeback=True
     hm_out = torch.empty_like(hm) if writeback else None
     kp_img = torch.empty((b, v, j, 2), dtype=torch.float32, device=dev)
     conf_n = torch.empty((b, v, j), dtype=torch.float32, device=dev)
-    kp3d = torch.empty((b, j, 3), dtype=torch.float32, device=dev)
+    sg = StepGather((b, j, 3), dev, world)
     st = _cabi.stream(dev)
 
     def step(timed):
         # the two C-ABI calls AlgebraicTriangulationNet.triangulate_from_heatmaps makes, with outputs preallocated
+        kp3d = sg.buffer()
         if timed:
             with k1:
                 rc = lib.mvx_soft_argmax_2d(_cabi.ptr(hm), b * v * j, h, w, 100.0, 1, _cabi.ptr(kp_hm), _cabi.ptr(hm_out), st)
@@ -134,20 +136,19 @@ def run_algebraic(args, dev, rank, world, n_views=4, frames=4096, writeback=True
                                              384.0 / h, _cabi.ptr(kp_img), _cabi.ptr(conf_n), _cabi.ptr(kp3d), st)
         if rc != 0:
             raise RuntimeError("mvx call failed: %s" % lib.mvx_last_error().decode())
-        if world > 1:
-            return gather(kp3d, frames * world)
-        return kp3d
+        sg.submit()
 
     # the drop-in class path gives the same numbers as the preallocated calls
     ref3d = net.triangulate_from_heatmaps(hm[:8], conf[:8], proj[:8], (384, 384))[0]
-    out = step(False)
+    step(False)
+    out = sg.gathered()
     own = out[rank * frames: rank * frames + 8] if world > 1 else out[:8]
     assert torch.equal(own, ref3d)
     # sanity: synthetic joints are recovered to within the blob noise
     err = (own.cpu().numpy() - case["joints_3d"][:8]).__abs__().max()
     assert err < 80.0, "triangulated joints are %g mm from the synthetic ground truth" % err
 
-    ms = timed_loop(step, args, dev, world)
+    ms = timed_loop(step, args, dev, world, sg)
     bytes_per_launch = frames * v * j * h * w * 4 * (2 if writeback else 1) + frames * v * j * 8
     roof = {"bound": "hbm", "kernel": "soft_argmax_2d_reg<9>", "achieved": bytes_per_launch / (k1.mean_ms() * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
@@ -166,8 +167,10 @@ def run_volumetric(args, dev, rank, world, frames=64):
     feats, proj, coord, vconf, vols = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
     k3 = EventTimer()
     k4 = EventTimer()
+    sg = StepGather((frames, 17, 3), dev, world)
 
     def step(timed):
+        dst = sg.buffer()
         if timed:
             with k3:
                 u = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
@@ -177,12 +180,11 @@ def run_volumetric(args, dev, rank, world, frames=64):
             u = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
             kp, _ = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
         del u
-        if world > 1:
-            return gather(kp, frames * world)
-        return kp
+        dst.copy_(kp)
+        sg.submit()
 
     step(False)
-    ms = timed_loop(step, args, dev, world)
+    ms = timed_loop(step, args, dev, world, sg)
     n_vox = 64 ** 3
     b3 = frames * (4 * 32 * 96 * 96 * 4 + n_vox * 12 + 32 * n_vox * 4)
     b4 = frames * (17 * n_vox * 4 * 2 + n_vox * 12)
@@ -227,7 +229,7 @@ def run_ransac(args, dev, rank, world, frames=4096):
     kp = torch.empty((b, v, j, 2), dtype=torch.int64, device=dev)
     kp_f64 = torch.empty((b, v, j, 2), dtype=torch.float64, device=dev)
     out = torch.empty((b, j, 3), dtype=torch.float64, device=dev)
-    kp3d = torch.empty((b, j, 3), dtype=torch.float32, device=dev)
+    sg = StepGather((b, j, 3), dev, world)
     masks = torch.empty((b, j), dtype=torch.int32, device=dev)
     st = _cabi.stream(dev)
     ka, kr = EventTimer(), EventTimer()
@@ -235,7 +237,7 @@ def run_ransac(args, dev, rank, world, frames=4096):
     def launch_argmax():
         return lib.mvx_heatmap_argmax(_cabi.ptr(hm), b * v * j, h, w, 384.0 / w, 384.0 / h, _cabi.ptr(kp), st)
 
-    def launch_ransac():
+    def launch_ransac(kp3d):
         kp_f64.copy_(kp)
         rc = lib.mvx_triangulate_ransac(_cabi.ptr(proj), _cabi.ptr(kp_f64), _cabi.ptr(pairs), b, v, j, n_iters, 15.0, 1,
                                         _cabi.ptr(out), _cabi.ptr(masks), st)
@@ -243,22 +245,24 @@ def run_ransac(args, dev, rank, world, frames=4096):
         return rc
 
     def step(timed):
+        kp3d = sg.buffer()
         if timed:
             with ka:
                 rc = launch_argmax()
             with kr:
-                rc |= launch_ransac()
+                rc |= launch_ransac(kp3d)
         else:
-            rc = launch_argmax() | launch_ransac()
+            rc = launch_argmax() | launch_ransac(kp3d)
         if rc != 0:
             raise RuntimeError("mvx call failed: %s" % lib.mvx_last_error().decode())
-        return gather(kp3d, frames * world) if world > 1 else kp3d
+        sg.submit()
 
-    got = step(False)
+    step(False)
+    got = sg.gathered()
     own = got[rank * frames: rank * frames + 8] if world > 1 else got[:8]
     err = (own.cpu().numpy() - case["joints_3d"][:8]).__abs__().max()
     assert err < 80.0, "triangulated joints are %g mm from the synthetic ground truth" % err
-    ms = timed_loop(step, args, dev, world)
+    ms = timed_loop(step, args, dev, world, sg)
     bytes_per_launch = frames * v * j * (h * w * 4 + 16)
     roof = {"bound": "hbm", "kernel": "heatmap_argmax<9>", "achieved": bytes_per_launch / (ka.mean_ms() * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -273,22 +277,65 @@ def run_ransac(args, dev, rank, world, frames=4096):
     return ms, frames, roof, cfg, extra
 
 
-def gather(local_kp, total_frames):
-    """All-gather of the keypoints: RCCL on device tensors; in the single-GPU rehearsal, gloo on host copies."""
-    if dist.get_backend() == "gloo":
-        return sharding.all_gather_keypoints(local_kp.cpu(), total_frames).to(local_kp.device)
-    return sharding.all_gather_keypoints(local_kp, total_frames)
+class StepGather:
+    """The all-gather that ends a step, overlapped with the next step: step k writes its keypoints into buffer
+    k % 2 and its collective runs (on RCCL's stream) while step k + 1 computes; a buffer is written again only
+    after the collective that reads it has finished.  `drain()` completes everything before timing stops.
+    In the single-GPU rehearsal the same logic runs over gloo on host copies."""
+
+    def __init__(self, local_shape, dev, world):
+        self.world = world
+        self.dev = dev
+        self.host = world > 1 and dist.get_backend() == "gloo"
+        self.buffers = [torch.empty(local_shape, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.pipe = None
+        if world > 1:
+            self.pipe = sharding.PipelinedKeypointGather(local_shape, torch.float32, "cpu" if self.host else dev, depth=2)
+            self.host_send = [torch.empty(local_shape, dtype=torch.float32) for _ in range(2)] if self.host else None
+        self.step = 0
+        self.last_slot = None
+
+    def buffer(self):
+        """The keypoint buffer of the step about to run (free of any collective still reading it)."""
+        slot = self.step % 2
+        if self.pipe is not None and self.pipe.pending[slot] is not None:
+            self.pipe.result(slot)
+        return self.buffers[slot]
+
+    def submit(self):
+        slot = self.step % 2
+        self.step += 1
+        if self.pipe is None:
+            return self.buffers[slot]
+        if self.host:
+            self.host_send[slot].copy_(self.buffers[slot])
+            self.last_slot = self.pipe.submit(self.host_send[slot])
+        else:
+            self.last_slot = self.pipe.submit(self.buffers[slot])
+        return None
+
+    def gathered(self):
+        """All ranks' keypoints of the last submitted step (waits for its collective)."""
+        if self.pipe is None:
+            return self.buffers[(self.step - 1) % 2]
+        return self.pipe.result(self.last_slot).to(self.dev)
+
+    def drain(self):
+        if self.pipe is not None:
+            self.pipe.drain()
 
 
-def timed_loop(step, args, dev, world):
+def timed_loop(step, args, dev, world, gather):
     for _ in range(args.warmup):
         step(False)
+    gather.drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    gather.drain()   # every step's all-gather has completed inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)

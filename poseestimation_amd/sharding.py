@@ -50,3 +50,42 @@ def all_gather_keypoints(local_keypoints, n_frames_total, group=None):
         return gathered
     parts = [gathered[r * biggest: r * biggest + sizes[r]] for r in range(world)]
     return torch.cat(parts, dim=0)
+
+
+class PipelinedKeypointGather:
+    """All-gather of equally sized keypoint shards that overlaps with the next step's kernels.
+
+    `submit(local_keypoints)` starts the collective (asynchronously, on the backend's own stream for RCCL) into
+    one of `depth` receive buffers and returns the slot; the caller must hand over a different tensor for each
+    slot in flight (a step writes its keypoints into buffer k % depth) because the collective reads it while
+    the next step already runs.  Before a slot is reused its previous collective is waited for; `result(slot)`
+    waits and returns the gathered (world * n_local, J, 3) tensor; `drain()` waits for everything outstanding
+    (call it before timing stops)."""
+
+    def __init__(self, local_shape, dtype, device, depth=2, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.depth = depth
+        self.recv = [torch.empty((self.world * local_shape[0],) + tuple(local_shape[1:]), dtype=dtype, device=device)
+                     for _ in range(depth)]
+        self.pending = [None] * depth
+        self.count = 0
+
+    def submit(self, local_keypoints):
+        slot = self.count % self.depth
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+        self.pending[slot] = dist.all_gather_into_tensor(self.recv[slot], local_keypoints, group=self.group,
+                                                         async_op=True)
+        self.count += 1
+        return slot
+
+    def result(self, slot):
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        return self.recv[slot]
+
+    def drain(self):
+        for slot in range(self.depth):
+            self.result(slot)

@@ -145,6 +145,20 @@ for total in (7, 8, 1):
     full = sharding.all_gather_keypoints(local, total)
     want = torch.arange(total, dtype=torch.float32).view(-1, 1, 1).expand(-1, 17, 3) * 1.5
     assert full.shape == (total, 17, 3) and torch.equal(full, want), (rank, total)
+# pipelined form: several steps in flight, each step's keypoints in its own buffer
+pipe = sharding.PipelinedKeypointGather((5, 17, 3), torch.float32, "cpu", depth=2)
+bufs = [torch.empty(5, 17, 3) for _ in range(2)]
+slots = []
+for step in range(5):
+    buf = bufs[step % 2]
+    if step >= 2:
+        got = pipe.result(slots[step - 2])          # also frees the buffer this step is about to overwrite
+        assert torch.equal(got[:5], torch.full((5, 17, 3), float(step - 2))) and \
+            torch.equal(got[5:], torch.full((5, 17, 3), 100.0 + step - 2)), (rank, step)
+    buf.fill_(float(step) + 100.0 * rank)
+    slots.append(pipe.submit(buf))
+pipe.drain()
+assert torch.equal(pipe.recv[0][5:], torch.full((5, 17, 3), 104.0)) and torch.equal(pipe.recv[1][:5], torch.full((5, 17, 3), 3.0))
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
