@@ -34,6 +34,7 @@ from poseestimation_amd.mvn.models.triangulation import AlgebraicTriangulationNe
 from poseestimation_amd.mvn.utils import op  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+ALL_GATHER_MS = None    # one keypoint all-gather on its own (N > 1), measured after the timed loop
 
 
 def algebraic_head():
@@ -324,6 +325,22 @@ class StepGather:
         if self.pipe is not None:
             self.pipe.drain()
 
+    def exposed_ms(self, repeats=10):
+        """Duration of one all-gather on its own (nothing to overlap with), host-visible, median."""
+        if self.pipe is None:
+            return None
+        self.drain()
+        ts = []
+        for _ in range(repeats):
+            dist.barrier()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            self.submit()
+            self.drain()
+            torch.cuda.synchronize(self.dev)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts) * 1e3)
+
 
 def timed_loop(step, args, dev, world, gather):
     for _ in range(args.warmup):
@@ -344,6 +361,8 @@ def timed_loop(step, args, dev, world, gather):
         t = torch.tensor([secs], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
+        global ALL_GATHER_MS
+        ALL_GATHER_MS = gather.exposed_ms()
     return secs * 1e3 / args.steps
 
 
@@ -437,6 +456,8 @@ def main():
         else:
             cpu = cpu_baseline_algebraic(16 if args.workload == "stream16" else 4, 64 if args.workload == "stream16" else 256)
 
+    if ALL_GATHER_MS is not None:
+        extra["keypoint_all_gather_alone_ms"] = ALL_GATHER_MS
     if rank == 0:
         line = {"metric": metric, "value": frames * world / (ms * 1e-3), "unit": "frames/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
