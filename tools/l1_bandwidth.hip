@@ -10,6 +10,7 @@
 // mode 0: every lane a consecutive float4 (1 KB contiguous per wave instruction)
 // mode 1: 8 lanes per 128-byte line, the 8 lines of a wave scattered over a 16 KB window (unprojection taps)
 // mode 2: like 1 but every wave instruction touches a single line (all 8 groups the same line)
+// mode 3: 16 lanes per 256 contiguous bytes (two adjacent lines), four such pairs scattered per wave instruction
 __global__ __launch_bounds__(256) void hammer(const float4* __restrict__ buf, int iters, int mode, float* sink) {
     const int lane = threadIdx.x & 63, q = lane & 7, grp = lane >> 3;
     const float4* base = buf + (size_t)(blockIdx.x & 255) * 1024;  // 16 KB window per CU-ish
@@ -24,6 +25,10 @@ __global__ __launch_bounds__(256) void hammer(const float4* __restrict__ buf, in
             else if (mode == 1) line = __builtin_amdgcn_readlane(h, 0) * 7u + grp * 13u + k * 5u;
             else line = __builtin_amdgcn_readlane(h, 0) + k;
             const float4* p = mode == 0 ? base + ((k * 64 + lane + i) & 1023) : base + ((line & 127u) * 8 + q);
+            if (mode == 3) {
+                const unsigned pair = (__builtin_amdgcn_readlane(h, 0) * 7u + (lane >> 4) * 13u + k * 5u) & 63u;
+                p = base + pair * 16 + (lane & 15);
+            }
             const float4 v = *p;
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
@@ -44,7 +49,7 @@ int main() {
     CHECK(hipGetDeviceProperties(&prop, 0));
     const double ghz = prop.clockRate / 1e6;
     const int cus = prop.multiProcessorCount;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         for (int per_cu : {1, 2, 4, 8}) {
             const int blocks = cus * per_cu, iters = 2000;
             hipLaunchKernelGGL(hammer, dim3(blocks), dim3(256), 0, 0, buf, 10, mode, sink);
