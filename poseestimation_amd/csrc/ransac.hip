@@ -28,9 +28,10 @@ __device__ __forceinline__ void take(Best& b, bool& nan_seen, float v, int i) {
     b.i = up ? i : b.i;
 }
 
-// NV > 0: the map is exactly NV * 256 float4 and every load is issued before the first comparison;
-// NV == 0: 16-byte loads in a loop; NV < 0: scalar loads (map size or alignment rules 16-byte loads out).
-template <int NV>
+// NV > 0: the map is at most NV * 256 float4 (exactly that many with EXACT) and every load is issued before the
+// first comparison, slots past the end holding -inf, which never wins; NV == 0: 16-byte loads in a loop;
+// NV < 0: scalar loads (map size or alignment rules 16-byte loads out).
+template <int NV, bool EXACT>
 __global__ __launch_bounds__(kArgmaxThreads) void heatmap_argmax(const float* __restrict__ maps, int hw, int w,
                                                                  float scale_x, float scale_y,
                                                                  long long* __restrict__ out) {
@@ -43,8 +44,12 @@ __global__ __launch_bounds__(kArgmaxThreads) void heatmap_argmax(const float* __
     if (NV > 0) {
         const float4v* m4 = reinterpret_cast<const float4v*>(map);
         float4v f[NV > 0 ? NV : 1];
+        const int n4 = hw >> 2;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) f[k] = __builtin_nontemporal_load(m4 + k * kArgmaxThreads + tid);
+        for (int k = 0; k < NV; ++k) {
+            f[k] = float4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (EXACT || k * kArgmaxThreads + tid < n4) f[k] = __builtin_nontemporal_load(m4 + k * kArgmaxThreads + tid);
+        }
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int i = 4 * (k * kArgmaxThreads + tid);
@@ -321,16 +326,21 @@ extern "C" int mvx_heatmap_argmax(const float* heatmaps, int64_t n_maps, int h, 
     if (per_cu < 1) per_cu = 1;
     const size_t cap_lds = per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
     const dim3 grid(static_cast<unsigned>(n_maps)), block(kArgmaxThreads);
-    if (vec && hw == 256 * 4 * 9)  // 96 x 96
-        hipLaunchKernelGGL(heatmap_argmax<9>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
-    else if (vec && hw == 256 * 4 * 4)  // 64 x 64
-        hipLaunchKernelGGL(heatmap_argmax<4>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
-    else if (vec && hw == 256 * 4 * 16)  // 128 x 128
-        hipLaunchKernelGGL(heatmap_argmax<16>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
-    else if (vec)
-        hipLaunchKernelGGL(heatmap_argmax<0>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
-    else
-        hipLaunchKernelGGL(heatmap_argmax<-1>, grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out);
+#define MVX_LAUNCH_ARGMAX(NV, EXACT) \
+    hipLaunchKernelGGL((heatmap_argmax<NV, EXACT>), grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out)
+    const int n4 = hw / 4;
+    if (!vec) MVX_LAUNCH_ARGMAX(-1, false);
+    else if (n4 == 256 * 9) MVX_LAUNCH_ARGMAX(9, true);    // 96 x 96
+    else if (n4 == 256 * 4) MVX_LAUNCH_ARGMAX(4, true);    // 64 x 64
+    else if (n4 == 256 * 16) MVX_LAUNCH_ARGMAX(16, true);  // 128 x 128
+    else if (n4 <= 256 * 2) MVX_LAUNCH_ARGMAX(2, false);
+    else if (n4 <= 256 * 4) MVX_LAUNCH_ARGMAX(4, false);
+    else if (n4 <= 256 * 6) MVX_LAUNCH_ARGMAX(6, false);
+    else if (n4 <= 256 * 9) MVX_LAUNCH_ARGMAX(9, false);
+    else if (n4 <= 256 * 12) MVX_LAUNCH_ARGMAX(12, false);
+    else if (n4 <= 256 * 16) MVX_LAUNCH_ARGMAX(16, false);
+    else MVX_LAUNCH_ARGMAX(0, false);
+#undef MVX_LAUNCH_ARGMAX
     MVX_CHECK_LAUNCH("mvx_heatmap_argmax");
     return MVX_OK;
 }

@@ -2,9 +2,9 @@
 //
 // HBM traffic per heatmap: one read of h*w floats, 8 bytes of coordinates, and (optionally) one write of
 // h*w floats.  The register kernel keeps the whole map in VGPRs between the max, the exp-sum and the
-// normalised write-back, so each element crosses HBM exactly once in each direction; the LDS kernel does
-// the same through a shared-memory tile for shapes the register kernel is not instantiated for; maps that
-// do not fit LDS are re-read from global memory (L2) per pass.
+// normalised write-back, so each element crosses HBM exactly once in each direction (any map of up to 16384
+// elements whose width is a multiple of 4); the LDS kernel does the same through a shared-memory tile for
+// the other shapes; maps that do not fit LDS are re-read from global memory (L2) per pass.
 //
 // Arithmetic: t = float32(x * multiplier); m = max t (exact); e = exp(t - m) in float32;
 // S = sum e, Sx = sum e*col, Sy = sum e*row in float64; x = Sx/S, y = Sy/S rounded once to float32.
@@ -87,27 +87,33 @@ __device__ __forceinline__ void store_f4(float4* p, const float4& v, bool nt) {
     }
 }
 
-// h*w == THREADS*4*NV and w % 4 == 0: the map lives in NV float4 registers per thread.
-template <int THREADS, int NV>
-__global__ __launch_bounds__(THREADS) void soft_argmax_2d_reg(const float* __restrict__ hm, int w, float mult,
+// w % 4 == 0 and h*w <= THREADS*4*NV: the map lives in NV float4 registers per thread.  EXACT: h*w is exactly
+// THREADS*4*NV (no guards); otherwise float4 slots past the end of the map hold -inf, which neither the maximum
+// nor the sums see (exp gives 0, max(x, 0) gives 0), and are not written back.
+template <int THREADS, int NV, bool EXACT>
+__global__ __launch_bounds__(THREADS) void soft_argmax_2d_reg(const float* __restrict__ hm, int hw, int w, float mult,
                                                                int softmax, float* __restrict__ coords,
                                                                float* __restrict__ out) {
     constexpr int kThreads = THREADS;
     __shared__ BlockReduce<THREADS / 64> red;
     const int tid = threadIdx.x;
     const size_t map = blockIdx.x;
-    constexpr int HW = kThreads * 4 * NV;
-    const float4* src = reinterpret_cast<const float4*>(hm + map * HW);
+    const int n4 = hw >> 2;
+    const float4* src = reinterpret_cast<const float4*>(hm + map * static_cast<size_t>(hw));
 
     float4 v[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = load_f4(src + k * kThreads + tid, true);
+    for (int k = 0; k < NV; ++k) {
+        v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (EXACT || k * kThreads + tid < n4) v[k] = load_f4(src + k * kThreads + tid, true);
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         v[k].x *= mult;
         v[k].y *= mult;
         v[k].z *= mult;
         v[k].w *= mult;
+        if (!EXACT && k * kThreads + tid >= n4) v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
 
     float m = 0.0f;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(THREADS) void soft_argmax_2d_reg(const float* __res
             v[k].z = fmaxf(v[k].z, 0.0f);
             v[k].w = fmaxf(v[k].w, 0.0f);
         }
-        accumulate4(v[k], row, col, s, sx, sy);
+        if (EXACT || k * kThreads + tid < n4) accumulate4(v[k], row, col, s, sx, sy);
         row += row_step;
         col += col_step;
         if (col >= w) {
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(THREADS) void soft_argmax_2d_reg(const float* __res
     }
     if (out != nullptr) {
         const float inv = softmax ? static_cast<float>(1.0 / s) : 1.0f;
-        float4* dst = reinterpret_cast<float4*>(out + map * HW);
+        float4* dst = reinterpret_cast<float4*>(out + map * static_cast<size_t>(hw));
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             float4 p = v[k];
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(THREADS) void soft_argmax_2d_reg(const float* __res
             p.y *= inv;
             p.z *= inv;
             p.w *= inv;
-            store_f4(dst + k * kThreads + tid, p, true);
+            if (EXACT || k * kThreads + tid < n4) store_f4(dst + k * kThreads + tid, p, true);
         }
     }
 }
@@ -254,19 +260,30 @@ extern "C" int mvx_soft_argmax_2d(const float* heatmaps, int64_t n_maps, int h, 
     } else {
         const int64_t in_flight = (heatmaps_out != nullptr ? 72 : 144) * 1024;
         per_cu = static_cast<int>((in_flight + static_cast<int64_t>(hw) * 2) / (static_cast<int64_t>(hw) * 4));
+        if (per_cu < 2) per_cu = 2;  // one workgroup per CU cannot hide its own latency (112 x 112: 4.3 vs 5.7 TB/s)
     }
     if (per_cu < 1) per_cu = 1;
     const size_t cap_lds = per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
     // (256, 384, 576 and 768 threads per map were measured within 1 % of each other at the same residency.)
-    if (vec_ok && hw == 256 * 4 * 9) {  // 96 x 96
-        hipLaunchKernelGGL((soft_argmax_2d_reg<256, 9>), grid, block, cap_lds, st, heatmaps, w, multiplier, softmax,
-                           coords, heatmaps_out);
-    } else if (vec_ok && hw == 256 * 4 * 4) {  // 64 x 64
-        hipLaunchKernelGGL((soft_argmax_2d_reg<256, 4>), grid, block, cap_lds, st, heatmaps, w, multiplier, softmax,
-                           coords, heatmaps_out);
-    } else if (vec_ok && hw == 256 * 4 * 16) {  // 128 x 128
-        hipLaunchKernelGGL((soft_argmax_2d_reg<256, 16>), grid, block, cap_lds, st, heatmaps, w, multiplier, softmax,
-                           coords, heatmaps_out);
+#define MVX_LAUNCH_REG(NV, EXACT)                                                                                   \
+    hipLaunchKernelGGL((soft_argmax_2d_reg<256, NV, EXACT>), grid, block, cap_lds, st, heatmaps, hw, w, multiplier,   \
+                       softmax, coords, heatmaps_out)
+    const int n4 = hw / 4;
+    if (vec_ok && n4 <= 256 * 16) {
+        // the map in registers: exact sizes (64 x 64, 96 x 96, 128 x 128) without guards, others in the smallest
+        // guarded instantiation that holds them
+        if (n4 == 256 * 9) MVX_LAUNCH_REG(9, true);
+        else if (n4 == 256 * 4) MVX_LAUNCH_REG(4, true);
+        else if (n4 == 256 * 16) MVX_LAUNCH_REG(16, true);
+        else if (n4 <= 256 * 1) MVX_LAUNCH_REG(1, false);
+        else if (n4 <= 256 * 2) MVX_LAUNCH_REG(2, false);
+        else if (n4 <= 256 * 3) MVX_LAUNCH_REG(3, false);
+        else if (n4 <= 256 * 4) MVX_LAUNCH_REG(4, false);
+        else if (n4 <= 256 * 6) MVX_LAUNCH_REG(6, false);
+        else if (n4 <= 256 * 9) MVX_LAUNCH_REG(9, false);
+        else if (n4 <= 256 * 12) MVX_LAUNCH_REG(12, false);
+        else MVX_LAUNCH_REG(16, false);
+#undef MVX_LAUNCH_REG
     } else if (static_cast<size_t>(hw) * sizeof(float) <= 64 * 1024) {
         hipLaunchKernelGGL(soft_argmax_2d_any<true>, grid, block, static_cast<size_t>(hw) * sizeof(float), st,
                            heatmaps, h, w, multiplier, softmax, coords, heatmaps_out);

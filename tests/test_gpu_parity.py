@@ -68,7 +68,11 @@ def test_soft_argmax_2d_golden_cases(name):
 
 
 @pytest.mark.parametrize("shape", [(3, 5, 64, 64), (2, 3, 128, 128), (2, 4, 20, 28), (1, 2, 97, 53), (1, 2, 150, 130),
-                                   (2, 1, 1, 7), (1, 1, 1, 1)])
+                                   (2, 1, 1, 7), (1, 1, 1, 1),
+                                   # guarded register kernel: every instantiation, sizes just below / at a boundary
+                                   (2, 3, 80, 80), (2, 2, 72, 96), (3, 2, 56, 56), (1, 3, 112, 112), (2, 2, 48, 64),
+                                   (2, 3, 2, 4), (1, 2, 32, 32), (1, 2, 33, 32), (1, 2, 96, 100), (1, 2, 127, 128),
+                                   (1, 2, 64, 48), (1, 2, 100, 60), (1, 2, 129, 128)])
 @pytest.mark.parametrize("softmax", [True, False])
 def test_soft_argmax_2d_shapes(shape, softmax):
     rng = np.random.default_rng(sum(shape))

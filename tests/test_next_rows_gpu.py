@@ -58,7 +58,10 @@ def _ransac_net(heatmaps=None, direct=True, view_pairs="sampled"):
 # ---- arg-max keypoints ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,image", [((2, 4, 17, 96, 96), (384, 384)), ((1, 2, 3, 7, 9), (50, 100)),
                                          ((3, 1, 2, 64, 64), (256, 256)), ((1, 1, 1, 1, 1), (4, 4)),
-                                         ((1, 3, 2, 33, 31), (384, 300))])
+                                         ((1, 3, 2, 33, 31), (384, 300)), ((2, 2, 3, 80, 80), (320, 320)),
+                                         ((1, 2, 3, 72, 96), (288, 384)), ((1, 2, 2, 112, 112), (448, 448)),
+                                         ((1, 1, 2, 128, 128), (512, 512)), ((1, 2, 2, 130, 132), (512, 512)),
+                                         ((1, 2, 2, 4, 8), (16, 32))])
 def test_heatmap_argmax_matches_oracle(shape, image):
     rng = np.random.default_rng(sum(shape))
     hm = rng.standard_normal(shape).astype(np.float32)
