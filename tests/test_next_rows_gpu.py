@@ -20,7 +20,7 @@ import mvn_oracle as orc
 from poseestimation_amd import _cabi, synth
 from poseestimation_amd.mvn.models import triangulation as tri
 from poseestimation_amd.realtime import POINT_CHANGE, UNITY_JOINTS, RealtimeTail, unity_points
-from poseestimation_amd.savgol_filer import SAVGOLFilter, fit_window, savgol_device
+from poseestimation_amd.savgol_filer import SAVGOLFilter, savgol_device
 
 pytestmark = pytest.mark.gpu
 
