@@ -151,6 +151,21 @@ int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * mvx_soft_argmax_3d for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference: same operation and
+ * same results as mvx_soft_argmax_3d (mvn/utils/op.py:84-96, 50-81), but the partial records live in a fixed
+ * MVX_SOFT_ARGMAX_3D_STATIC_BYTES array inside the library (one copy per GPU, held until the process ends)
+ * instead of a caller-owned workspace; the call allocates and frees nothing.  Shapes whose
+ * mvx_soft_argmax_3d_workspace_bytes() exceed that size are rejected with MVX_ERR_WORKSPACE (17 volumes of
+ * 64^3: up to 12 frames per call).  All calls on one GPU share the array: calls that overlap in time on one
+ * GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not.
+ */
+#define MVX_SOFT_ARGMAX_3D_STATIC_BYTES (8u << 20)
+int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes,
+                              int sx, int sy, int sz, float multiplier, int softmax, float* out, float* volumes_out,
+                              void* stream);
+
+/*
  * Coordinate volumes of VolumetricTriangulationNet.forward: replaces the per-frame meshgrid / scale / rotate
  * loop of mvn/models/triangulation.py:341-385 (and mvn/utils/volumetric.py:102-114) with one launch.
  * For frame b and voxel (i0, i1, i2):  g = position[b] + step * (i0, i1, i2);  out = rotation[b] . (g - center[b])

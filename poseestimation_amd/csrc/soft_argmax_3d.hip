@@ -13,6 +13,8 @@
 // write-back the volumes cross HBM a second time on the read side.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "mvx_common.h"
 
 namespace mvx {
@@ -283,10 +285,11 @@ extern "C" size_t mvx_soft_argmax_3d_workspace_bytes(int64_t n_frames, int n_vol
     return static_cast<size_t>(n_frames) * n_volumes * (n_seg * mvx::kRecord * sizeof(double) + sizeof(float2));
 }
 
-extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes,
-                                  int sx, int sy, int sz, float multiplier, int softmax, float* out,
-                                  float* volumes_out, void* workspace, size_t workspace_bytes, void* stream) {
-    using namespace mvx;
+namespace mvx {
+namespace {
+int soft_argmax_3d_any(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes, int sx, int sy,
+                       int sz, float multiplier, int softmax, float* out, float* volumes_out, void* workspace,
+                       size_t workspace_bytes, void* stream) {
     MVX_REQUIRE(n_frames >= 0 && n_volumes >= 0 && sx > 0 && sy > 0 && sz > 0, MVX_ERR_INVALID_ARGUMENT,
                 "mvx_soft_argmax_3d: bad shape n_frames=%lld n_volumes=%d grid=%dx%dx%d", (long long)n_frames,
                 n_volumes, sx, sy, sz);
@@ -344,4 +347,68 @@ extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volu
         MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (normalize)");
     }
     return MVX_OK;
+}
+}  // namespace
+}  // namespace mvx
+
+extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes,
+                                  int sx, int sy, int sz, float multiplier, int softmax, float* out,
+                                  float* volumes_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return mvx::soft_argmax_3d_any(volumes, coords_volume, n_frames, n_volumes, sx, sy, sz, multiplier, softmax, out,
+                                   volumes_out, workspace, workspace_bytes, stream);
+}
+
+// ---- the same operation for callers that cannot allocate -------------------------------------------------
+// The partial records and the (max, 1 / sum) pairs live in a fixed array of the code object instead of a
+// caller-owned workspace.  Every GPU holds its own copy of the array at its own address; the host-side name
+// `scratch` is only a handle for hipGetSymbolAddress, never a pointer to pass to a kernel.
+static __device__ __align__(256) unsigned char scratch[MVX_SOFT_ARGMAX_3D_STATIC_BYTES];
+
+namespace mvx {
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex scratch_mutex;
+void* scratch_of_device[kMaxDevices];  // device address of `scratch` per HIP device, resolved on first use
+
+int static_scratch(void** ptr) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        set_error("mvx_soft_argmax_3d_static: hipGetDevice failed or device %d out of range: %s", dev,
+                  hipGetErrorString(e));
+        return MVX_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (scratch_of_device[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            set_error("mvx_soft_argmax_3d_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                      hipGetErrorString(e));
+            return MVX_ERR_HIP;
+        }
+        scratch_of_device[dev] = p;
+    }
+    *ptr = scratch_of_device[dev];
+    return MVX_OK;
+}
+}  // namespace
+}  // namespace mvx
+
+extern "C" int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, int64_t n_frames,
+                                         int n_volumes, int sx, int sy, int sz, float multiplier, int softmax,
+                                         float* out, float* volumes_out, void* stream) {
+    using namespace mvx;
+    const size_t need = mvx_soft_argmax_3d_workspace_bytes(n_frames, n_volumes, sx, sy, sz);
+    MVX_REQUIRE(need <= MVX_SOFT_ARGMAX_3D_STATIC_BYTES, MVX_ERR_WORKSPACE,
+                "mvx_soft_argmax_3d_static: %lld frames x %d volumes of %dx%dx%d need %zu bytes of partial records, the "
+                "built-in buffer holds %zu; use mvx_soft_argmax_3d with a caller-owned workspace",
+                (long long)n_frames, n_volumes, sx, sy, sz, need, (size_t)MVX_SOFT_ARGMAX_3D_STATIC_BYTES);
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != MVX_OK) return rc;
+    // every record and pair that the later passes read is rewritten by the earlier pass of the same call, so the
+    // contents a previous call left behind need no clearing
+    return soft_argmax_3d_any(volumes, coords_volume, n_frames, n_volumes, sx, sy, sz, multiplier, softmax, out,
+                              volumes_out, ws, MVX_SOFT_ARGMAX_3D_STATIC_BYTES, stream);
 }

@@ -1,0 +1,88 @@
+"""mvx_soft_argmax_3d_static (the 3-D soft-argmax that allocates nothing: its partial records live in a fixed
+array inside the library) against mvx_soft_argmax_3d with a caller-owned workspace, through the C ABI.
+Both run the same kernels, so the outputs must be bit-identical -- on two calls in a row, the second with a
+smaller input (the array keeps the first call's records), and for shapes beyond the array's size the call
+must refuse.  Collected last on purpose."""
+import numpy as np
+import pytest
+import torch
+
+import mvn_oracle as orc
+from poseestimation_amd import _cabi, synth
+
+pytestmark = pytest.mark.gpu
+
+STATIC_BYTES = 8 << 20
+
+
+def _run(lib, name, vols, coord, softmax, multiplier, writeback):
+    dev = vols.device
+    b, j, sx, sy, sz = vols.shape
+    out = torch.full((b, j, 3), float("nan"), dtype=torch.float32, device=dev)
+    vout = torch.full_like(vols, float("nan")) if writeback else None
+    st = _cabi.stream(dev)
+    cp = _cabi.ptr(coord) if coord is not None else None
+    if name == "static":
+        rc = lib.mvx_soft_argmax_3d_static(_cabi.ptr(vols), cp, b, j, sx, sy, sz, multiplier, int(softmax),
+                                           _cabi.ptr(out), _cabi.ptr(vout), st)
+    else:
+        need = lib.mvx_soft_argmax_3d_workspace_bytes(b, j, sx, sy, sz)
+        ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
+        rc = lib.mvx_soft_argmax_3d(_cabi.ptr(vols), cp, b, j, sx, sy, sz, multiplier, int(softmax), _cabi.ptr(out),
+                                    _cabi.ptr(vout), _cabi.ptr(ws), ws.numel() * 8, st)
+    torch.cuda.synchronize(dev)
+    return rc, out, vout
+
+
+def test_static_scratch_entry_matches_workspace_entry():
+    lib = _cabi.load()
+    dev = torch.device("cuda:0")
+    big = synth.volumetric_case(41, 3, 2, n_joints=17, volume_size=64)     # 3 frames x 17 volumes of 64^3
+    small = synth.volumetric_case(42, 1, 2, n_joints=5, volume_size=16)    # then 1 frame x 5 volumes of 16^3
+    for case, softmax, mult, writeback in ((big, True, 1.0, True), (small, True, 2.5, True),
+                                           (big, False, 1.0, False), (small, True, 1.0, False)):
+        vols = torch.from_numpy(case["volumes"]).to(dev)
+        coord = torch.from_numpy(case["coord_volumes"]).to(dev)
+        rc_s, out_s, vout_s = _run(lib, "static", vols, coord, softmax, mult, writeback)
+        rc_w, out_w, vout_w = _run(lib, "workspace", vols, coord, softmax, mult, writeback)
+        assert rc_s == 0 and rc_w == 0, lib.mvx_last_error()
+        assert torch.equal(out_s, out_w)
+        assert not torch.isnan(out_s).any()
+        if writeback:
+            assert torch.equal(vout_s, vout_w)
+        # and both are the reference's answer
+        oc, _ = orc.integrate_tensor_3d_with_coordinates(case["volumes"] * np.float32(mult), case["coord_volumes"], softmax)
+        assert (np.abs(out_s.cpu().numpy() - oc) <= 1e-3 + 1e-6 * np.abs(oc)).all()
+    # index-space variant (no coordinate volume)
+    vols = torch.from_numpy(small["volumes"]).to(dev)
+    rc_s, out_s, _ = _run(lib, "static", vols, None, True, 1.0, False)
+    rc_w, out_w, _ = _run(lib, "workspace", vols, None, True, 1.0, False)
+    assert rc_s == 0 and rc_w == 0 and torch.equal(out_s, out_w)
+
+
+def test_static_scratch_entry_rejects_oversize_and_allocates_nothing():
+    lib = _cabi.load()
+    dev = torch.device("cuda:0")
+    # 13 frames x 17 volumes of 64^3 need more records than the built-in array holds: refused before any launch
+    assert lib.mvx_soft_argmax_3d_workspace_bytes(13, 17, 64, 64, 64) > STATIC_BYTES
+    assert lib.mvx_soft_argmax_3d_workspace_bytes(12, 17, 64, 64, 64) <= STATIC_BYTES
+    dummy = torch.zeros(16, device=dev)
+    rc = lib.mvx_soft_argmax_3d_static(_cabi.ptr(dummy), None, 13, 17, 64, 64, 64, 1.0, 1, _cabi.ptr(dummy), None,
+                                       _cabi.stream(dev))
+    assert rc == _cabi.MVX_ERR_WORKSPACE
+    assert b"built-in buffer" in lib.mvx_last_error()
+    # device memory in use does not move across calls of the entry point
+    case = synth.volumetric_case(43, 2, 2, n_joints=17, volume_size=32)
+    vols = torch.from_numpy(case["volumes"]).to(dev)
+    coord = torch.from_numpy(case["coord_volumes"]).to(dev)
+    out = torch.empty((2, 17, 3), dtype=torch.float32, device=dev)
+    vout = torch.empty_like(vols)
+    args = (_cabi.ptr(vols), _cabi.ptr(coord), 2, 17, 32, 32, 32, 1.0, 1, _cabi.ptr(out), _cabi.ptr(vout), _cabi.stream(dev))
+    assert lib.mvx_soft_argmax_3d_static(*args) == 0
+    torch.cuda.synchronize(dev)
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for _ in range(5):
+        assert lib.mvx_soft_argmax_3d_static(*args) == 0
+    torch.cuda.synchronize(dev)
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0
