@@ -1,6 +1,6 @@
 """Throughput of the multi-view triangulation path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload algebraic|volumetric|stream16|ransac]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload algebraic|volumetric|stream16|ransac|sharded]
 
 A step is one pass of the path over one resident batch of synthetic frames:
   algebraic  (default: the headline configuration) 4096 frames x 4 views x 17 joints of 96x96 heatmaps per GPU:
@@ -11,12 +11,20 @@ A step is one pass of the path over one resident batch of synthetic frames:
   stream16   16 views: p50 latency of one frame and throughput at 1024 frames.
   ransac     the reference's third triangulation model on the algebraic shapes: arg-max keypoints of 4096 x 4 x 17
              heatmaps, then RANSAC over every view pair + DLT over the inliers + Huber refinement per joint.
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds its own batch (weak scaling,
-frames sharded across ranks) and each step ends with the RCCL all-gather of the (frames, 17, 3) keypoints, which
-runs on RCCL's stream while the next step computes; every all-gather has completed before the clock stops.
-Rank 0 prints one JSON line; `value` is the whole-job frames/s with inputs resident in HBM.
+  sharded    65 536 frames in all, split into contiguous shards over the ranks (strong scaling): every frame goes
+             through the algebraic leg and then the volumetric leg (cuboid centred on the pelvis the algebraic leg
+             found), and one all-gather returns both sets of keypoints to every rank.
+`--gpus N` with N > 1 and no launcher around it starts the N ranks itself (fresh interpreters, one per GPU, before
+this process has touched the GPU); under torch.distributed.run the ranks it started are used as they are.  With
+N > 1 the algebraic / volumetric / ransac workloads give every rank its own batch (weak scaling) and end each step
+with the RCCL all-gather of the (frames, 17, 3) keypoints, which runs on RCCL's stream while the next step computes;
+every all-gather has completed before the clock stops.  Rank 0 prints one JSON line; `value` is the whole-job
+frames/s with inputs resident in HBM.  The default run also measures the other configurations once the headline is
+done and reports them under extra.configs (skip with --no-extra).
 """
 import argparse
+import copy
+import hashlib
 import json
 import os
 import sys
@@ -29,7 +37,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from poseestimation_amd import _cabi, sharding, synth  # noqa: E402
+from poseestimation_amd import _cabi, launch, sharding, synth  # noqa: E402
 from poseestimation_amd.mvn.models.triangulation import AlgebraicTriangulationNet  # noqa: E402
 from poseestimation_amd.mvn.utils import op  # noqa: E402
 
@@ -64,15 +72,38 @@ class EventTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
 
 
-def measured_traffic(kernel, frames, views, writeback):
+KERNEL_SOURCES = {   # the files a kernel is compiled from: a counter record is valid for exactly these bytes
+    "soft_argmax_2d_reg<9>": ("soft_argmax_2d.hip", "mvx_common.h"),
+    "heatmap_argmax<9>": ("ransac.hip", "mvx_common.h"),
+    "unproject": ("unproject.hip", "mvx_common.h"),
+    "soft_argmax_3d": ("soft_argmax_3d.hip", "mvx_common.h"),
+}
+
+
+def kernel_source_hash(kernel):
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[kernel]:
+        with open(os.path.join(ROOT, "poseestimation_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def measured_traffic(kernel, shape):
     """HBM bytes per launch of `kernel` from the rocprofv3 counter passes stored under profiles/ (collected
-    with the same launch shape in a separate profiled run: counters cannot be read from inside this process)."""
+    with the same launch shape in a separate profiled run: counters cannot be read from inside this process).
+    A record counts only if it was taken on the kernel sources this library was built from (their SHA-256 is
+    stored with it) and on the same launch shape; otherwise the traffic is reported as unknown."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[kernel]
     except (OSError, KeyError, ValueError):
-        return None, None
-    if (rec["frames"], rec["views"], rec["heatmap_writeback"]) != (frames, views, writeback):
-        return None, None
+        return None, "no counter record for %s" % kernel
+    if rec.get("shape") != shape:
+        return None, "counter record is for another launch shape (%s)" % (rec.get("shape"),)
+    try:
+        if rec.get("source_sha256") != kernel_source_hash(kernel):
+            return None, "stale: the kernel sources changed after the counter passes (%s)" % rec.get("source")
+    except OSError:
+        return None, "kernel sources not found"
     return rec["hbm_bytes_per_launch"], rec["source"]
 
 
@@ -155,12 +186,58 @@ def run_algebraic(args, dev, rank, world, n_views=4, frames=4096, writeback=True
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"], roof["traffic_source"] = measured_traffic("soft_argmax_2d_reg<9>", frames, v, writeback)
+    roof["traffic"], roof["traffic_source"] = measured_traffic(
+        "soft_argmax_2d_reg<9>", {"frames": frames, "views": v, "joints": j, "heatmap_writeback": writeback})
     extra = {"dlt_kernel_ms": k2.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err)}
     cfg = {"workload": "algebraic: soft-argmax 2D + confidence-weighted DLT, %d frames/GPU x %d views x 17 joints, 96x96 heatmaps"
                        % (frames, v), "frames_per_gpu": frames, "views": v, "joints": j, "heatmap_writeback": writeback,
            "parallelism": "frames sharded over %d GPU(s), all-gather of keypoints" % world}
     return ms, frames, roof, cfg, extra
+
+
+def torch_unproject_softmax(feats, proj, coord, frame, voxels):
+    """Float64 torch evaluation on the device of the unprojection of `frame` at the flat voxel indices `voxels`
+    (projection, the reference's pixel mapping ix = x / H * (W - 1), iy = y / W * (H - 1), bilinear taps with zero
+    padding, zero behind the camera, softmax over views): an independent check of the kernel, not the oracle."""
+    v, c, h, w = feats.shape[1:]
+    pts = coord[frame].reshape(-1, 3)[voxels].double()
+    pts = torch.cat([pts, torch.ones_like(pts[:, :1])], dim=1)
+    per_view = []
+    for vi in range(v):
+        uvw = pts @ proj[frame, vi].double().t()
+        behind = uvw[:, 2] <= 0
+        z = torch.where(uvw[:, 2] == 0, torch.ones_like(uvw[:, 2]), uvw[:, 2])
+        ix, iy = uvw[:, 0] / z / h * (w - 1), uvw[:, 1] / z / w * (h - 1)
+        x0, y0 = torch.floor(ix), torch.floor(iy)
+        img = feats[frame, vi].double()
+        acc = torch.zeros((c, pts.shape[0]), dtype=torch.float64, device=feats.device)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                xi, yi = x0 + dx, y0 + dy
+                wgt = (1 - (ix - xi).abs()) * (1 - (iy - yi).abs())
+                ok = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1) & ~behind
+                tap = img[:, yi.clamp(0, h - 1).long(), xi.clamp(0, w - 1).long()]
+                acc += tap * (wgt * ok).unsqueeze(0)
+        per_view.append(acc)
+    stack = torch.stack(per_view)
+    return (stack * torch.softmax(stack, dim=0)).sum(0)
+
+
+def check_volumetric(feats, proj, coord, vols, unprojected, keypoints, frames_to_check):
+    """The volumes and keypoints of a few frames against float64 torch on the device."""
+    n_vox = coord.shape[1] * coord.shape[2] * coord.shape[3]
+    voxels = torch.arange(0, n_vox, 997, device=feats.device)
+    worst_u = worst_k = 0.0
+    for f in frames_to_check:
+        want = torch_unproject_softmax(feats, proj, coord, f, voxels)
+        got = unprojected[f].reshape(unprojected.shape[1], -1)[:, voxels].double()
+        worst_u = max(worst_u, float((got - want).abs().max()))
+        p = torch.softmax(vols[f].reshape(vols.shape[1], -1).double(), dim=1)
+        want_k = p @ coord[f].reshape(-1, 3).double()
+        worst_k = max(worst_k, float((keypoints[f].double() - want_k).abs().max()))
+    assert worst_u < 1e-4, "unprojected volumes are %g from the float64 evaluation" % worst_u
+    assert worst_k < 1e-3, "volumetric keypoints are %g mm from the float64 evaluation" % worst_k
+    return worst_u, worst_k
 
 
 def run_volumetric(args, dev, rank, world, frames=64):
@@ -180,11 +257,15 @@ def run_volumetric(args, dev, rank, world, frames=64):
         else:
             u = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
             kp, _ = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
-        del u
         dst.copy_(kp)
         sg.submit()
+        return u
 
-    step(False)
+    # sanity before timing: frames from every part of the batch against float64 torch on the device
+    u = step(False)
+    own = sg.gathered()[rank * frames: (rank + 1) * frames] if world > 1 else sg.gathered()
+    err_u, err_k = check_volumetric(feats, proj, coord, vols, u, own, sorted({0, frames // 7, frames // 2, frames - 1}))
+    del u
     ms = timed_loop(step, args, dev, world, sg)
     n_vox = 64 ** 3
     b3 = frames * (4 * 32 * 96 * 96 * 4 + n_vox * 12 + 32 * n_vox * 4)
@@ -193,14 +274,175 @@ def run_volumetric(args, dev, rank, world, frames=64):
             "achieved": b3 / (k3.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": b3, "avg_launch_ms": k3.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"], roof["traffic_source"] = measured_traffic("unproject", {"frames": frames, "views": 4, "method": "softmax"})
     # the unprojection gathers 4 taps x 32 channels x 4 B per voxel and view through the vector L1; a CU returns
     # 46 B/clk for loads of that shape when everything hits (tools/l1_bandwidth.hip: 28.2 TB/s over the chip)
     tap_bytes = frames * n_vox * 4 * 512
     extra = {"soft_argmax_3d_ms": k4.mean_ms(), "soft_argmax_3d_GBps": b4 / (k4.mean_ms() * 1e-3) / 1e9,
-             "unproject_tap_TBps": tap_bytes / (k3.mean_ms() * 1e-3) / 1e12, "measured_l1_gather_ceiling_TBps": 28.2}
+             "soft_argmax_3d_frac_of_hbm_peak": b4 / (k4.mean_ms() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "unproject_tap_TBps": tap_bytes / (k3.mean_ms() * 1e-3) / 1e12, "measured_l1_gather_ceiling_TBps": 28.2,
+             "max_abs_error_unproject_vs_float64_torch": err_u, "max_abs_error_keypoints_vs_float64_torch_mm": err_k}
     cfg = {"workload": "volumetric: unproject 4 views x 32ch 96x96 -> 64^3 (softmax) + 3-D soft-argmax of 17 volumes, %d frames/GPU"
                        % frames, "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world}
     return ms, frames, roof, cfg, extra
+
+
+def run_sharded(args, dev, rank, world, total=65536, alg_block=4096, vol_block=64):
+    """BASELINE configs[3]: `total` frames in contiguous shards over the ranks, algebraic then volumetric leg per
+    frame, one all-gather of both keypoint sets.  The shard is streamed through resident input blocks (4096 frames
+    of heatmaps, 64 frames of features and volumes: synthetic inputs are re-used block after block, outputs are
+    written per frame), so that a shard of any size fits in HBM; every kernel runs on every frame."""
+    lo, hi = sharding.shard_bounds(total, rank, world)
+    n_local = hi - lo
+    alg_block = max(1, min(alg_block, n_local))
+    vol_block = max(1, min(vol_block, n_local))
+    lib = _cabi.load()
+    st = _cabi.stream(dev)
+    a = synth.device_algebraic_case(1234 + 3 + rank, alg_block, 4, dev)
+    hm, conf, proj = a["heatmaps"], a["confidences"], a["proj"]
+    _, v, j, h, w = hm.shape
+    vcase = synth.device_volumetric_case(1234 + 3 + rank, vol_block, 4, dev)
+    feats, proj_hm, vols = vcase["features"], vcase["proj"], vcase["volumes"]
+    S, side = 64, 2500.0
+    n_vox = S ** 3
+    # outputs: per-frame keypoints of both legs side by side (one collective moves both)
+    kp_all = torch.zeros((n_local, 2 * j, 3), dtype=torch.float32, device=dev)
+    kp3d_blk = torch.empty((alg_block, j, 3), dtype=torch.float32, device=dev)
+    kp_hm = torch.empty((alg_block * v, j, 2), dtype=torch.float32, device=dev)
+    hm_out = torch.empty_like(hm)
+    kp_img = torch.empty((alg_block, v, j, 2), dtype=torch.float32, device=dev)
+    conf_n = torch.empty((alg_block, v, j), dtype=torch.float32, device=dev)
+    coord = torch.empty((vol_block, S, S, S, 3), dtype=torch.float32, device=dev)
+    unproj = torch.empty((vol_block, 32, S, S, S), dtype=torch.float32, device=dev)
+    vols_out = torch.empty_like(vols)
+    vkp_blk = torch.empty((vol_block, j, 3), dtype=torch.float32, device=dev)
+    ws3 = torch.empty(lib.mvx_unproject_workspace_bytes(vol_block, 4, 32, 96, 96) // 4 + 4, dtype=torch.float32, device=dev)
+    ws4 = torch.empty(lib.mvx_soft_argmax_3d_workspace_bytes(vol_block, j, S, S, S) // 8 + 1, dtype=torch.float64, device=dev)
+    rot = torch.eye(3, dtype=torch.float32, device=dev).reshape(1, 9).repeat(vol_block, 1).contiguous()
+    step_mm = float(np.float32(side / (S - 1)))
+    t_alg, t_unp, t_k4 = EventTimer(), EventTimer(), EventTimer()
+    t_leg_a, t_leg_v = EventTimer(), EventTimer()
+
+    def fail(rc):
+        if rc != 0:
+            raise RuntimeError("mvx call failed: %s" % lib.mvx_last_error().decode())
+
+    def algebraic_leg(timed):
+        for f0 in range(0, n_local, alg_block):
+            nf = min(alg_block, n_local - f0)
+            tm = t_alg if (timed and nf == alg_block) else None
+            if tm is not None:
+                tm.__enter__()
+            rc = lib.mvx_soft_argmax_2d(_cabi.ptr(hm), nf * v * j, h, w, 100.0, 1, _cabi.ptr(kp_hm), _cabi.ptr(hm_out), st)
+            if tm is not None:
+                tm.__exit__()
+            rc |= lib.mvx_algebraic_glue_dlt(_cabi.ptr(proj), _cabi.ptr(kp_hm), _cabi.ptr(conf), nf, v, j, 384.0 / w,
+                                             384.0 / h, _cabi.ptr(kp_img), _cabi.ptr(conf_n), _cabi.ptr(kp3d_blk), st)
+            fail(rc)
+            kp_all[f0:f0 + nf, :j].copy_(kp3d_blk[:nf])
+
+    def volumetric_leg(timed):
+        for f0 in range(0, n_local, vol_block):
+            nf = min(vol_block, n_local - f0)
+            center = kp_all[f0:f0 + nf, synth.PELVIS_JOINT].contiguous()   # the pelvis the algebraic leg found
+            position = center - side / 2
+            fail(lib.mvx_build_coord_volumes(_cabi.ptr(position), _cabi.ptr(center), _cabi.ptr(rot), nf, S, S, S, step_mm,
+                                             step_mm, step_mm, 0, _cabi.ptr(coord), st))
+            tm = t_unp if (timed and nf == vol_block) else None
+            if tm is not None:
+                tm.__enter__()
+            rc = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj_hm), _cabi.ptr(coord), None, nf, 4, 32, 96, 96, S, S, S,
+                                   _cabi.AGG_SOFTMAX, _cabi.ptr(unproj), _cabi.ptr(ws3), ws3.numel() * 4, st)
+            if tm is not None:
+                tm.__exit__()
+            fail(rc)
+            tm = t_k4 if (timed and nf == vol_block) else None
+            if tm is not None:
+                tm.__enter__()
+            rc = lib.mvx_soft_argmax_3d(_cabi.ptr(vols), _cabi.ptr(coord), nf, j, S, S, S, 1.0, 1, _cabi.ptr(vkp_blk),
+                                        _cabi.ptr(vols_out), _cabi.ptr(ws4), ws4.numel() * 8, st)
+            if tm is not None:
+                tm.__exit__()
+            fail(rc)
+            kp_all[f0:f0 + nf, j:].copy_(vkp_blk[:nf])
+
+    gather_host = world > 1 and dist.get_backend() == "gloo"
+    gathered = [None]
+
+    def exchange():
+        if world == 1:
+            gathered[0] = kp_all
+        elif gather_host:
+            gathered[0] = sharding.all_gather_keypoints(kp_all.cpu(), total)
+        else:
+            gathered[0] = sharding.all_gather_keypoints(kp_all, total)
+
+    def step(timed):
+        if timed:
+            with t_leg_a:
+                algebraic_leg(True)
+            with t_leg_v:
+                volumetric_leg(True)
+        else:
+            algebraic_leg(False)
+            volumetric_leg(False)
+        exchange()
+
+    # sanity before timing: the first blocks against the drop-in class path and float64 torch on the device
+    step(False)
+    torch.cuda.synchronize(dev)
+    net = algebraic_head()
+    nchk = min(8, alg_block)
+    ref3d = net.triangulate_from_heatmaps(hm[:nchk], conf[:nchk], proj[:nchk], (384, 384))[0]
+    assert torch.equal(kp_all[:nchk, :j], ref3d)
+    err = float((kp_all[:nchk, :j].cpu().numpy() - a["joints_3d"][:nchk]).__abs__().max())
+    assert err < 80.0, "triangulated joints are %g mm from the synthetic ground truth" % err
+    # the last volumetric block is still in coord / unproj / vkp_blk
+    last0 = ((n_local - 1) // vol_block) * vol_block
+    nlast = n_local - last0
+    err_u, err_k = check_volumetric(feats[:nlast], proj_hm[:nlast], coord[:nlast], vols[:nlast], unproj[:nlast],
+                                    vkp_blk[:nlast], sorted({0, nlast - 1}))
+    full = gathered[0]
+    assert tuple(full.shape) == (total, 2 * j, 3)
+    assert torch.equal(full[lo:hi].to(dev), kp_all)
+    assert bool(torch.isfinite(full).all())
+
+    class _NoPipe:
+        def drain(self):
+            pass
+
+        def exposed_ms(self, repeats=5):
+            if world == 1:
+                return None
+            ts = []
+            for _ in range(repeats):
+                dist.barrier()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                exchange()
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts) * 1e3)
+
+    ms = timed_loop(step, args, dev, world, _NoPipe())
+    b3 = vol_block * (4 * 32 * 96 * 96 * 4 + n_vox * 12 + 32 * n_vox * 4)
+    b4 = vol_block * (17 * n_vox * 4 * 2 + n_vox * 12)
+    b1 = alg_block * v * j * (h * w * 4 * 2 + 8)
+    roof = {"bound": "hbm", "kernel": "unproject (channel-last copy + unproject_tile32<softmax>), %d-frame blocks" % vol_block,
+            "achieved": b3 / (t_unp.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "algorithmic_bytes_per_launch": b3, "avg_launch_ms": t_unp.mean_ms()}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    extra = {"frames_this_rank": n_local, "algebraic_leg_ms": t_leg_a.mean_ms(), "volumetric_leg_ms": t_leg_v.mean_ms(),
+             "soft_argmax_2d_GBps": b1 / (t_alg.mean_ms() * 1e-3) / 1e9,
+             "soft_argmax_3d_GBps": b4 / (t_k4.mean_ms() * 1e-3) / 1e9,
+             "max_abs_error_vs_synthetic_truth_mm": err, "max_abs_error_unproject_vs_float64_torch": err_u,
+             "max_abs_error_keypoints_vs_float64_torch_mm": err_k}
+    cfg = {"workload": "sharded: %d frames in all, algebraic (4 views x 17 joints, heatmap write-back) then volumetric "
+                       "(unproject to 64^3 + 3-D soft-argmax) per frame, one all-gather of both keypoint sets" % total,
+           "frames_total": total, "frames_per_gpu": [b - a_ for a_, b in (sharding.shard_bounds(total, r, world)
+                                                                         for r in range(world))],
+           "parallelism": "contiguous frame shards over %d GPU(s), all-gather of (frames, 34, 3) keypoints" % world}
+    return ms, n_local, roof, cfg, extra
 
 
 def cpu_baseline_ransac(sample_frames):
@@ -269,7 +511,8 @@ def run_ransac(args, dev, rank, world, frames=4096):
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": ka.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"], roof["traffic_source"] = measured_traffic("heatmap_argmax<9>", frames, v, False)
+    roof["traffic"], roof["traffic_source"] = measured_traffic(
+        "heatmap_argmax<9>", {"frames": frames, "views": v, "joints": j, "heatmap_writeback": False})
     extra = {"ransac_kernel_and_casts_ms": kr.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err),
              "mean_inlier_views": float(torch.bitwise_and(masks.view(-1, 1) >> torch.arange(4, device=dev), 1).sum(1).float().mean())}
     cfg = {"workload": "ransac: heatmap arg-max + RANSAC (all 6 view pairs) + inlier DLT + Huber refinement, "
@@ -380,7 +623,8 @@ def latency_p50(dev, n_views=16, launches=1000):
         net.triangulate_from_heatmaps(hm, conf, proj, (384, 384))
         torch.cuda.synchronize(dev)
         ts.append(time.perf_counter() - t0)
-    wrapper = (float(np.percentile(ts, 50) * 1e6), float(np.percentile(ts, 99) * 1e6))
+    out = {"batch1_16view_latency_p50_us": float(np.percentile(ts, 50) * 1e6),
+           "batch1_16view_latency_p99_us": float(np.percentile(ts, 99) * 1e6)}
     # the same frame through the bare C entry point with caller-owned outputs (what a serving loop would do)
     lib = _cabi.load()
     b, v, j, h, w = hm.shape
@@ -400,7 +644,53 @@ def latency_p50(dev, n_views=16, launches=1000):
         lib.mvx_algebraic_forward(*args)
         torch.cuda.synchronize(dev)
         ts.append(time.perf_counter() - t0)
-    return wrapper + (float(np.percentile(ts, 50) * 1e6),)
+    out["batch1_16view_c_abi_latency_p50_us"] = float(np.percentile(ts, 50) * 1e6)
+    out["batch1_16view_c_abi_latency_p99_us"] = float(np.percentile(ts, 99) * 1e6)
+    return out
+
+
+METRICS = {
+    "algebraic": "triangulated frames/sec (4-view, 17-joint)",
+    "volumetric": "volumetric frames/sec (4-view unproject to 64^3 + 3-D soft-argmax, 17 joints)",
+    "ransac": "RANSAC-triangulated frames/sec (4-view, 17-joint)",
+    "stream16": "triangulated frames/sec (16-view, 17-joint)",
+    "sharded": "triangulated frames/sec (4-view, 17-joint; algebraic + volumetric leg per frame, 65536 frames sharded)",
+}
+
+
+def run_workload(name, args, dev, rank, world):
+    """-> one result record: metric, value (whole-job frames/s), ms_per_step, scaling, config, roofline, extra."""
+    global ALL_GATHER_MS
+    ALL_GATHER_MS = None
+    extra = {}
+    scaling = "weak"
+    if name == "algebraic":
+        ms, frames, roof, cfg, extra = run_algebraic(args, dev, rank, world, 4, args.frames or 4096, not args.no_writeback)
+    elif name == "volumetric":
+        ms, frames, roof, cfg, extra = run_volumetric(args, dev, rank, world, args.frames or 64)
+    elif name == "ransac":
+        ms, frames, roof, cfg, extra = run_ransac(args, dev, rank, world, args.frames or 4096)
+    elif name == "sharded":
+        total = args.frames or 65536
+        ms, frames, roof, cfg, extra = run_sharded(args, dev, rank, world, total)
+        scaling = "strong"
+    else:
+        ms, frames, roof, cfg, extra = run_algebraic(args, dev, rank, world, 16, args.frames or 1024, not args.no_writeback)
+        if rank == 0:
+            lat = latency_p50(dev)
+            extra.update(lat)
+    units = (args.frames or 65536) if name == "sharded" else frames * world
+    if ALL_GATHER_MS is not None:
+        extra["keypoint_all_gather_alone_ms"] = ALL_GATHER_MS
+    return {"metric": METRICS[name], "value": units / (ms * 1e-3), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roof, "extra": extra}
+
+
+def with_steps(args, steps, warmup):
+    a = copy.copy(args)
+    a.steps, a.warmup, a.frames = steps, warmup, 0
+    return a
 
 
 def main():
@@ -408,63 +698,69 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="algebraic", choices=["algebraic", "volumetric", "stream16", "ransac"])
-    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
+    ap.add_argument("--workload", default="algebraic", choices=sorted(METRICS))
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (sharded: frames in all); default: the workload's")
     ap.add_argument("--no-writeback", action="store_true", help="algebraic: skip the normalised-heatmap output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="default run: skip the other configurations after the headline")
     args = ap.parse_args()
+
+    # MVX_BENCH_REHEARSAL=1 rehearses the multi-rank path on a single GPU: every rank uses cuda:0 and the
+    # collectives run over gloo on host copies (RCCL needs one device per rank).  Not a measurement mode.
+    rehearsal = os.environ.get("MVX_BENCH_REHEARSAL") == "1"
+    if args.gpus > 1 and not launch.in_launched_rank():
+        # No launcher around us: start the ranks ourselves.  Nothing above has touched the GPU (device_count does
+        # not initialise HIP), and this process never will: it only relays rank 0's line.
+        visible = torch.cuda.device_count()
+        if visible < args.gpus and not rehearsal:
+            print("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, visible), file=sys.stderr)
+            sys.exit(2)
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # MVX_BENCH_REHEARSAL=1 rehearses the multi-rank path on a single GPU: every rank uses cuda:0 and the
-    # collectives run over gloo on host copies (RCCL needs one device per rank).  Not a measurement mode.
-    rehearsal = os.environ.get("MVX_BENCH_REHEARSAL") == "1"
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         dist.init_process_group("gloo" if rehearsal else "nccl", init_method="env://")
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     _cabi.load()  # fails loudly if libmvx.so was not built
 
-    extra = {}
-    if args.workload == "algebraic":
-        ms, frames, roof, cfg, extra = run_algebraic(args, dev, rank, world, 4, args.frames or 4096, not args.no_writeback)
-        metric = "triangulated frames/sec (4-view, 17-joint)"
-    elif args.workload == "volumetric":
-        ms, frames, roof, cfg, extra = run_volumetric(args, dev, rank, world, args.frames or 64)
-        metric = "volumetric frames/sec (4-view unproject to 64^3 + 3-D soft-argmax, 17 joints)"
-    elif args.workload == "ransac":
-        ms, frames, roof, cfg, extra = run_ransac(args, dev, rank, world, args.frames or 4096)
-        metric = "RANSAC-triangulated frames/sec (4-view, 17-joint)"
-    else:
-        ms, frames, roof, cfg, extra = run_algebraic(args, dev, rank, world, 16, args.frames or 1024, not args.no_writeback)
-        metric = "triangulated frames/sec (16-view, 17-joint)"
-        if rank == 0:
-            p50, p99, c_p50 = latency_p50(dev)
-            extra["batch1_16view_latency_p50_us"] = p50
-            extra["batch1_16view_latency_p99_us"] = p99
-            extra["batch1_16view_c_abi_latency_p50_us"] = c_p50
+    line = run_workload(args.workload, args, dev, rank, world)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        if args.workload == "volumetric":
+        if args.workload in ("volumetric", "sharded"):
             cpu = cpu_baseline_volumetric(4)
         elif args.workload == "ransac":
             cpu = cpu_baseline_ransac(16)
         else:
             cpu = cpu_baseline_algebraic(16 if args.workload == "stream16" else 4, 64 if args.workload == "stream16" else 256)
+    line["cpu_baseline"] = cpu
 
-    if ALL_GATHER_MS is not None:
-        extra["keypoint_all_gather_alone_ms"] = ALL_GATHER_MS
+    # the other configurations of the path, measured after the headline so that one driver-timed run covers them
+    plain_default = args.workload == "algebraic" and not args.no_extra and not args.frames and not args.no_writeback
+    if plain_default:
+        others = {}
+        todo = [("sharded_65536_frames", "sharded", with_steps(args, 2, 1))]
+        if world == 1:
+            todo = [("volumetric_64_frames", "volumetric", with_steps(args, 10, 2)),
+                    ("stream16", "stream16", with_steps(args, 10, 2))] + todo
+        for key, name, sub in todo:
+            torch.cuda.empty_cache()
+            rec = run_workload(name, sub, dev, rank, world)
+            others[key] = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                               "scaling", "config", "roofline", "extra")}
+        line["extra"]["configs"] = others
+
     if rank == 0:
-        line = {"metric": metric, "value": frames * world / (ms * 1e-3), "unit": "frames/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
-                "roofline": roof, "cpu_baseline": cpu, "extra": extra}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

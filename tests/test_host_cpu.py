@@ -175,6 +175,65 @@ def test_all_gather_keypoints_two_ranks_gloo(tmp_path):
     assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
 
 
+_STUB_RANK = r"""
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from poseestimation_amd import sharding
+fail_rank = int(sys.argv[2])
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if rank == fail_rank:
+    sys.exit(7)
+total = 65536
+a, b = sharding.shard_bounds(total, rank, world)
+local = torch.arange(a, b, dtype=torch.float32).view(-1, 1, 1).expand(-1, 34, 3).contiguous()   # the stub "step"
+full = sharding.all_gather_keypoints(local, total)
+ok = bool(torch.equal(full[:, 0, 0], torch.arange(total, dtype=torch.float32)))
+print("noise from rank", rank)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "frames": total, "ok": ok}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_spawn_ranks_runs_a_stub_step_over_gloo(tmp_path):
+    """The launcher bench.py uses for --gpus N without an outer launcher: N fresh ranks with the env:// variables,
+    rank 0's stdout relayed as the job's output, a failing rank fails the job."""
+    import io
+    import json
+
+    from poseestimation_amd import launch
+    script = tmp_path / "stub_rank.py"
+    script.write_text(_STUB_RANK)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for world in (2, 3):
+        out, err = io.StringIO(), io.StringIO()
+        rc = launch.spawn_ranks(world, [sys.executable, str(script), ROOT, "-1"], timeout=180, env=env, stdout=out, stderr=err)
+        assert rc == 0, err.getvalue()
+        lines = [l for l in out.getvalue().splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": world, "frames": 65536, "ok": True}
+        assert "noise from rank 1" in err.getvalue() and "noise from rank 1" not in out.getvalue()
+    out, err = io.StringIO(), io.StringIO()
+    assert launch.spawn_ranks(2, [sys.executable, str(script), ROOT, "1"], timeout=180, env=env, stdout=out, stderr=err) == 7
+    assert not launch.in_launched_rank({}) and launch.in_launched_rank({"RANK": "0", "WORLD_SIZE": "2"})
+    with pytest.raises(ValueError):
+        launch.spawn_ranks(0, ["true"])
+
+
+def test_bench_refuses_a_gpu_count_it_cannot_deliver():
+    """`bench.py --gpus N` never silently runs another number of ranks: with no launcher and fewer visible GPUs, or
+    under a launcher that started a different world size, it exits non-zero before touching a GPU."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MVX_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2 but 0 GPU(s) visible" in r.stderr and r.stdout == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655"))
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and r.stdout == ""
+
+
 def test_heatmap_projections_match_the_camera_loop():
     """The vectorised camera rescale + projection of the volumetric forward against the per-camera
     update_after_resize / projection it replaces; the caller's cameras stay untouched."""
