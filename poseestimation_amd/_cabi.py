@@ -90,6 +90,24 @@ def device_f32(t, name):
     return t.contiguous()
 
 
+def same_device(ref, ref_name, **tensors):
+    """Raises unless every tensor given by keyword (None entries are skipped) lives on `ref`'s device.  The kernels
+    receive raw addresses and run on `ref`'s GPU: a tensor from another GPU would be read as a foreign pointer
+    (the reference's torch ops raise a RuntimeError for mixed devices; MvxError is one)."""
+    for name, t in tensors.items():
+        if t is not None and t.device != ref.device:
+            raise MvxError("%s is on %s but %s is on %s: all tensors of one call must be on the same device"
+                           % (name, t.device, ref_name, ref.device))
+
+
+def forward_only(what, *tensors):
+    """The kernels record no autograd graph.  Raises when autograd is recording and one of `tensors` requires
+    grad: returning a detached result there would drop the gradient without a word."""
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        raise MvxError("%s is forward-only (no backward kernel): call it under torch.no_grad() or detach its inputs; "
+                       "training through this operation needs the reference's differentiable torch ops" % what)
+
+
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

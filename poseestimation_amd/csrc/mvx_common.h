@@ -29,6 +29,15 @@ void set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
+// Dynamic LDS to request (and not use) so that at most about `bytes_in_flight` of maps of `hw` floats are resident
+// per CU: HBM sustains more when the chip-wide window of open pages is small.  Never fewer than two workgroups per
+// CU (one cannot hide its own latency: 4.3 against 5.7 TB/s on 112 x 112 maps); 0 = no cap (8 or more fit).
+inline size_t residency_cap_lds(int hw, int64_t bytes_in_flight) {
+    int per_cu = static_cast<int>((bytes_in_flight + static_cast<int64_t>(hw) * 2) / (static_cast<int64_t>(hw) * 4));
+    if (per_cu < 2) per_cu = 2;
+    return per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device side: wave64 reductions through DPP ----------------------------------------------
@@ -96,6 +105,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // exp(d) for d <= 0 through v_exp_f32 (2^x): relative error about 1e-7, which the soft-argmax
 // tolerances leave ample room for (the sums it feeds are accumulated in float64).
 __device__ __forceinline__ float exp_neg(float d) { return __builtin_amdgcn_exp2f(d * 1.44269504088896340736f); }
+
+// max(t, 0) that keeps a NaN a NaN, as torch's relu does (fmaxf would return 0 for it).
+__device__ __forceinline__ float relu_keep_nan(float t) { return t > 0.0f ? t : (t != t ? t : 0.0f); }
 
 // Blocks b and b+8 share an XCD (and its L2).  Gives each XCD a contiguous range of work items so that
 // neighbouring items, which read the same inputs, meet in one L2.  Bijective for every grid size.

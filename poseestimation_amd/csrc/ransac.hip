@@ -322,9 +322,7 @@ extern "C" int mvx_heatmap_argmax(const float* heatmaps, int64_t n_maps, int h, 
     long long* out = reinterpret_cast<long long*>(keypoints);
     // A read-only stream runs fastest with about 144 KB of maps in flight per CU (4 workgroups of a 96 x 96 map);
     // LDS the kernel does not use is requested only to cap the residency at that.
-    int per_cu = static_cast<int>((144 * 1024 + static_cast<int64_t>(hw) * 2) / (static_cast<int64_t>(hw) * 4));
-    if (per_cu < 1) per_cu = 1;
-    const size_t cap_lds = per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
+    const size_t cap_lds = residency_cap_lds(hw, 144 * 1024);
     const dim3 grid(static_cast<unsigned>(n_maps)), block(kArgmaxThreads);
 #define MVX_LAUNCH_ARGMAX(NV, EXACT) \
     hipLaunchKernelGGL((heatmap_argmax<NV, EXACT>), grid, block, cap_lds, st, heatmaps, hw, w, scale_x, scale_y, out)

@@ -136,10 +136,10 @@ __global__ __launch_bounds__(THREADS) void soft_argmax_2d_reg(const float* __res
             v[k].z = exp_neg(v[k].z - m);
             v[k].w = exp_neg(v[k].w - m);
         } else {
-            v[k].x = fmaxf(v[k].x, 0.0f);
-            v[k].y = fmaxf(v[k].y, 0.0f);
-            v[k].z = fmaxf(v[k].z, 0.0f);
-            v[k].w = fmaxf(v[k].w, 0.0f);
+            v[k].x = relu_keep_nan(v[k].x);
+            v[k].y = relu_keep_nan(v[k].y);
+            v[k].z = relu_keep_nan(v[k].z);
+            v[k].w = relu_keep_nan(v[k].w);
         }
         if (EXACT || k * kThreads + tid < n4) accumulate4(v[k], row, col, s, sx, sy);
         row += row_step;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_2d_any(const float* __re
     double s = 0.0, sx = 0.0, sy = 0.0;
     for (int i = tid; i < hw; i += kThreads) {
         const float t = STAGED ? tile[i] : src[i] * mult;
-        const float e = softmax ? exp_neg(t - m) : fmaxf(t, 0.0f);
+        const float e = softmax ? exp_neg(t - m) : relu_keep_nan(t);
         if (STAGED) tile[i] = e;
         const int row = i / w, col = i - row * w;
         const double ed = e;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_2d_any(const float* __re
                 e = tile[i];
             } else {
                 const float t = src[i] * mult;
-                e = softmax ? exp_neg(t - m) : fmaxf(t, 0.0f);
+                e = softmax ? exp_neg(t - m) : relu_keep_nan(t);
             }
             dst[i] = e * inv;
         }
@@ -253,17 +253,7 @@ extern "C" int mvx_soft_argmax_2d(const float* heatmaps, int64_t n_maps, int h, 
     // and writes of the whole chip then stay inside a window of a few MB); LDS the kernel does not use is
     // requested only to cap the residency.  Without the write-back the stream is read-only and twice that
     // (4 workgroups) is best.
-    const char* be = getenv("MVX_SAM2D_BLOCKS_PER_CU");
-    int per_cu = 8;
-    if (be != nullptr) {
-        per_cu = atoi(be);
-    } else {
-        const int64_t in_flight = (heatmaps_out != nullptr ? 72 : 144) * 1024;
-        per_cu = static_cast<int>((in_flight + static_cast<int64_t>(hw) * 2) / (static_cast<int64_t>(hw) * 4));
-        if (per_cu < 2) per_cu = 2;  // one workgroup per CU cannot hide its own latency (112 x 112: 4.3 vs 5.7 TB/s)
-    }
-    if (per_cu < 1) per_cu = 1;
-    const size_t cap_lds = per_cu >= 8 ? 0 : (static_cast<size_t>(160) * 1024 / per_cu - 1024) / 1024 * 1024;
+    const size_t cap_lds = residency_cap_lds(hw, (heatmaps_out != nullptr ? 72 : 144) * 1024);
     // (256, 384, 576 and 768 threads per map were measured within 1 % of each other at the same residency.)
 #define MVX_LAUNCH_REG(NV, EXACT)                                                                                   \
     hipLaunchKernelGGL((soft_argmax_2d_reg<256, NV, EXACT>), grid, block, cap_lds, st, heatmaps, hw, w, multiplier,   \

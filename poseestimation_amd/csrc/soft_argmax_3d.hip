@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_partial(const float* 
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float e = softmax ? exp_neg(t[k][i] - mref) : fmaxf(t[k][i], 0.0f);
+                const float e = softmax ? exp_neg(t[k][i] - mref) : relu_keep_nan(t[k][i]);
                 const double ed = e;
                 s += ed;
                 sx = fma(ed, static_cast<double>(cx[k][i]), sx);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_normalize(const float
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float t = v[k] * mult;
-            p[k] = softmax ? exp_neg(t - st.x) * st.y : fmaxf(t, 0.0f);
+            p[k] = softmax ? exp_neg(t - st.x) * st.y : relu_keep_nan(t);
         }
         __builtin_nontemporal_store(p, reinterpret_cast<vec4f*>(vol_out + i));
     } else {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_normalize(const float
             if (i + k < n_total) {
                 const float2 st = stats[(i + k) / n_vox];
                 const float t = vol[i + k] * mult;
-                vol_out[i + k] = softmax ? exp_neg(t - st.x) * st.y : fmaxf(t, 0.0f);
+                vol_out[i + k] = softmax ? exp_neg(t - st.x) * st.y : relu_keep_nan(t);
             }
         }
     }

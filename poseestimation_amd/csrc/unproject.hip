@@ -449,8 +449,6 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
     const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
     const bool tiled = (C == 32) && (V <= kTileMaxViews) && (n_voxels % kTile == 0) && aligned16(volumes) &&
                        (aggregation != MVX_AGG_CONF || aligned16(vol_conf));
-    const char* pe = getenv("MVX_UNPROJ_PATH");  // testing knob: "generic" forces the generic kernel
-    const bool force_generic = pe != nullptr && pe[0] == 'g';
     const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V) * kTile * 20 + static_cast<size_t>(V) * 12 * 8;
     const double sx = static_cast<double>(w - 1) / static_cast<double>(h);  // ix = x / H * (W - 1)
     const double sy = static_cast<double>(h - 1) / static_cast<double>(w);  // iy = y / W * (H - 1)
@@ -473,7 +471,7 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
         const float* cd = coords + f0 * n_voxels * 3;
         const float* vc = vol_conf != nullptr ? vol_conf + f0 * V * C : nullptr;
         float* vo = volumes + f0 * C * n_voxels;
-        if (tiled && !force_generic) {
+        if (tiled) {
             const int64_t tiles = n_voxels / kTile;
             MVX_REQUIRE(nf * tiles <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
             const dim3 grid(static_cast<unsigned>(nf * tiles));

@@ -7,8 +7,10 @@ The heatmap backbone and the V2V volume network are not part of this package: th
 reference's own `mvn.models.pose_resnet` / `mvn.models.v2v` when that tree is importable, or passed in
 (`backbone=`, `volume_net=`).  State-dict keys (`backbone.*`, `process_features.*`, `volume_net.*`) are the
 reference's, so its checkpoints load with strict=True.  Forward-only: the triangulation ops record no
-autograd graph (the reference's algebraic path is not differentiable either, mvn/utils/multiview.py:166).
+autograd graph (the reference's algebraic path is not differentiable either, mvn/utils/multiview.py:166);
+a module in training mode called with autograd recording raises instead of returning detached results.
 """
+import contextlib
 import random
 import time
 
@@ -102,6 +104,7 @@ def ransac_triangulate_batch(proj_matricies, keypoints_2d, view_pairs, reproject
         raise ValueError("proj_matricies must have shape %s, got %s" % ((b, v, 3, 4), tuple(proj.shape)))
     if not 2 <= v <= 32:
         raise ValueError("RANSAC triangulation takes 2 to 32 views, got %d" % v)
+    _cabi.same_device(proj, "proj_matricies", keypoints_2d=keypoints_2d)
     points = keypoints_2d.to(torch.float64).contiguous()
     pairs = torch.as_tensor(np.ascontiguousarray(view_pairs) if isinstance(view_pairs, np.ndarray) else view_pairs)
     if pairs.dtype != torch.uint8 or pairs.dim() != 3 or pairs.shape[0] != b * j or pairs.shape[2] != 2:
@@ -183,6 +186,14 @@ class RANSACTriangulationNet(nn.Module):
         return out[0, 0].cpu().numpy(), inliers
 
 
+def _inference_guard(module):
+    """The triangulation kernels are forward-only.  A module in eval mode runs them without autograd, which is
+    what an inference caller of the reference gets under torch.no_grad().  A module in training mode does not
+    switch autograd off: the reference back-propagates through these steps (train.py:197-202, 281-290), so with
+    autograd recording the ops raise instead of handing back results that would silently train nothing."""
+    return contextlib.nullcontext() if module.training else torch.no_grad()
+
+
 class AlgebraicTriangulationNet(nn.Module):
     def __init__(self, config, device='cuda:0', backbone=None):
         super().__init__()
@@ -203,12 +214,15 @@ class AlgebraicTriangulationNet(nn.Module):
         heatmaps (B, V, J, h, w) raw backbone output; alg_confidences (B, V, J); proj_matricies (B, V, 3, 4)
         for image pixels; image_shape (H, W).  Returns (keypoints_3d (B, J, 3), keypoints_2d (B, V, J, 2) in
         image pixels, normalised heatmaps (B, V, J, h, w), confidences (B, V, J))."""
+        _cabi.forward_only("AlgebraicTriangulationNet.triangulate_from_heatmaps", heatmaps, alg_confidences,
+                           proj_matricies)
         hm = _cabi.device_f32(heatmaps, "heatmaps")
         b, v, j, h, w = hm.shape
         conf = _cabi.device_f32(alg_confidences, "alg_confidences").reshape(b, v, j)
         proj = _cabi.device_f32(proj_matricies, "proj_matricies")
         if tuple(proj.shape) != (b, v, 3, 4):
             raise ValueError("proj_matricies must have shape %s, got %s" % ((b, v, 3, 4), tuple(proj.shape)))
+        _cabi.same_device(hm, "heatmaps", alg_confidences=conf, proj_matricies=proj)
         hm_norm = torch.empty_like(hm)
         # one allocation for the small outputs: heatmap-pixel keypoints, image-pixel keypoints, confidences, joints
         n2, n1, n3 = b * v * j * 2, b * v * j, b * j * 3
@@ -245,7 +259,7 @@ class AlgebraicTriangulationNet(nn.Module):
         image_shape = tuple(images.shape[2:])
         heatmaps = heatmaps.view(batch_size, n_views, *heatmaps.shape[1:])
         alg_confidences = alg_confidences.view(batch_size, n_views, *alg_confidences.shape[1:])
-        with torch.no_grad():
+        with _inference_guard(self):
             keypoints_3d, keypoints_2d, heatmaps, alg_confidences = self.triangulate_from_heatmaps(
                 heatmaps, alg_confidences, proj_matricies, image_shape)
         _sync(device)
@@ -370,12 +384,12 @@ class VolumetricTriangulationNet(nn.Module):
         features = self.process_features(features)
         features = features.view(batch_size, n_views, *features.shape[1:])
 
-        with torch.no_grad():
+        with _inference_guard(self):
             volumes = op.unproject_heatmaps(features, proj_matricies, coord_volumes,
                                             volume_aggregation_method=self.volume_aggregation_method,
                                             vol_confidences=vol_confidences)
         volumes = self.volume_net(volumes)
-        with torch.no_grad():
+        with _inference_guard(self):
             vol_keypoints_3d, volumes = op.integrate_tensor_3d_with_coordinates(
                 volumes, coord_volumes, softmax=self.volume_softmax, multiplier=self.volume_multiplier)
         # same 7-tuple as the reference (triangulation.py:403)

@@ -112,8 +112,9 @@ def triangulate_point_from_multiple_views_linear(proj_matricies, points):
 def _dlt(proj, points, conf):
     """proj (B,V,3,4), points (B,V,J,2), conf (B,V,J) or None -> (B,J,3) on the device of `points`."""
     pts = _cabi.device_f32(points, "points")
-    P = _cabi.device_f32(proj, "proj_matricies").to(pts.device)
-    c = None if conf is None else _cabi.device_f32(conf, "confidences").to(pts.device)
+    P = _cabi.device_f32(proj, "proj_matricies")
+    c = None if conf is None else _cabi.device_f32(conf, "confidences")
+    _cabi.same_device(pts, "points", proj_matricies=P, confidences=c)
     b, v, j = pts.shape[:3]
     out = torch.zeros((b, j, 3), dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):

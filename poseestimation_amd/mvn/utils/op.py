@@ -1,7 +1,8 @@
 """Same functions and signatures as the reference's mvn/utils/op.py, running on the mvx HIP kernels.
 
-All functions are forward-only (no autograd graph is recorded), take HIP device tensors and return
-freshly allocated float32 tensors on the same device, launched on torch's current stream.
+All functions are forward-only (no autograd graph is recorded; they raise when autograd is recording and an
+input requires grad, rather than drop the gradient), take HIP device tensors and return freshly allocated
+float32 tensors on the same device, launched on torch's current stream.
 """
 import torch
 
@@ -9,6 +10,7 @@ from poseestimation_amd import _cabi
 
 
 def _soft_argmax_2d(heatmaps, softmax, multiplier, return_heatmaps):
+    _cabi.forward_only("integrate_tensor_2d", heatmaps)
     hm = _cabi.device_f32(heatmaps, "heatmaps")
     if hm.dim() != 4:
         raise ValueError("heatmaps must have shape (batch, n_heatmaps, h, w), got %s" % (tuple(hm.shape),))
@@ -36,6 +38,8 @@ def integrate_tensor_2d(heatmaps, softmax=True, *, multiplier=1.0, return_heatma
 
 
 def _soft_argmax_3d(volumes, coord_volumes, softmax, multiplier, return_volumes):
+    _cabi.forward_only("integrate_tensor_3d" if coord_volumes is None else "integrate_tensor_3d_with_coordinates",
+                       volumes, coord_volumes)
     vol = _cabi.device_f32(volumes, "volumes")
     if vol.dim() != 5:
         raise ValueError("volumes must have shape (batch, n_volumes, x, y, z), got %s" % (tuple(vol.shape),))
@@ -45,8 +49,7 @@ def _soft_argmax_3d(volumes, coord_volumes, softmax, multiplier, return_volumes)
         cv = _cabi.device_f32(coord_volumes, "coord_volumes")
         if tuple(cv.shape) != (b, sx, sy, sz, 3):
             raise ValueError("coord_volumes must have shape %s, got %s" % ((b, sx, sy, sz, 3), tuple(cv.shape)))
-        if cv.device != vol.device:
-            raise ValueError("volumes and coord_volumes are on different devices")
+        _cabi.same_device(vol, "volumes", coord_volumes=cv)
     coords = torch.empty((b, n, 3), dtype=torch.float32, device=vol.device)
     out = torch.empty_like(vol) if return_volumes else None
     lib = _cabi.load()
@@ -107,6 +110,7 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
         agg = _AGGREGATIONS[method]
     else:
         raise ValueError("Unknown volume_aggregation_method: {}".format(method))
+    _cabi.forward_only("unproject_heatmaps", heatmaps, proj_matricies, coord_volumes, vol_confidences)
     channels_last = _is_channels_last(heatmaps)
     feats = heatmaps if channels_last else _cabi.device_f32(heatmaps, "heatmaps")
     proj = _cabi.device_f32(proj_matricies, "proj_matricies")
@@ -124,6 +128,7 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
         vc = _cabi.device_f32(vol_confidences, "vol_confidences")
         if tuple(vc.shape) != (b, v, c):
             raise ValueError("vol_confidences must have shape %s, got %s" % ((b, v, c), tuple(vc.shape)))
+    _cabi.same_device(feats, "heatmaps", proj_matricies=proj, coord_volumes=cv, vol_confidences=vc)
     volumes = torch.empty((b, c) + vshape, dtype=torch.float32, device=feats.device)
     lib = _cabi.load()
     if channels_last:   # the maps are sampled where they lie: no layout copy, no workspace

@@ -127,6 +127,23 @@ def test_soft_argmax_2d_edge_cases():
     c1, _ = op.integrate_tensor_2d(view)
     c2, _ = op.integrate_tensor_2d(view.contiguous().float())
     assert torch.equal(c1, c2)
+    # a NaN from the backbone stays visible on both paths, as with torch's softmax and relu: the map that holds
+    # it gets NaN coordinates and (relu) a NaN at that pixel; the other maps are untouched
+    for shape in ((2, 3, 96, 96), (2, 3, 40, 36), (2, 3, 13, 11)):     # register kernel, guarded slots, any-shape kernel
+        clean = torch.randn(shape, device=dev())
+        bad = clean.clone()
+        bad[1, 2, 5, 7] = float("nan")
+        for softmax in (True, False):
+            c0, o0 = op.integrate_tensor_2d(clean, softmax)
+            c1, o1 = op.integrate_tensor_2d(bad, softmax)
+            assert torch.isnan(c1[1, 2]).all() and torch.isnan(o1[1, 2, 5, 7])
+            keep = torch.ones(shape[:2], dtype=torch.bool, device=dev())
+            keep[1, 2] = False
+            assert torch.equal(c1[keep], c0[keep]) and torch.equal(o1[keep], o0[keep])
+            if not softmax:
+                rest = torch.ones(shape[2:], dtype=torch.bool, device=dev())
+                rest[5, 7] = False
+                assert torch.equal(o1[1, 2][rest], o0[1, 2][rest])
     with pytest.raises(_cabi.MvxError):
         op.integrate_tensor_2d(torch.zeros(1, 1, 4, 4))      # CPU tensor: no fallback
     with pytest.raises(ValueError):
@@ -237,26 +254,43 @@ def test_unproject_full_size_tile_kernel(method):
     assert np.abs(out.reshape(32, -1)[:, sub] - ref).max() < UNPROJ_TOL
 
 
+def unproject_c_abi(feats, proj, coord, vconf, method, misalign_output=False):
+    """mvx_unproject called directly.  The tile kernel stores 16 bytes per lane, so a volume buffer that is only
+    4-byte aligned is served by the any-shape kernel: the way to run the same maps through both kernels."""
+    lib = _cabi.load()
+    b, v, c, h, w = feats.shape
+    vs = tuple(coord.shape[1:4])
+    agg = {"sum": _cabi.AGG_SUM, "conf": _cabi.AGG_CONF, "max": _cabi.AGG_MAX, "softmax": _cabi.AGG_SOFTMAX}[method]
+    n = b * c * vs[0] * vs[1] * vs[2]
+    buf = torch.empty(n + 4, dtype=torch.float32, device=feats.device)
+    out = buf[1:n + 1] if misalign_output else buf[:n]
+    assert (out.data_ptr() % 16 != 0) == misalign_output
+    ws = torch.empty(lib.mvx_unproject_workspace_bytes(b, v, c, h, w) // 4 + 4, dtype=torch.float32, device=feats.device)
+    rc = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(coord), _cabi.ptr(vconf), b, v, c, h, w, vs[0],
+                           vs[1], vs[2], agg, _cabi.ptr(out), _cabi.ptr(ws), ws.numel() * 4, _cabi.stream(feats.device))
+    assert rc == 0, lib.mvx_last_error()
+    return out.view(b, c, *vs)
+
+
 @pytest.mark.parametrize("side,views", [(2500.0, 4), (2500.0, 3), (9000.0, 4), (30000.0, 2)])
-def test_unproject_kernel_paths_agree(side, views, monkeypatch):
+def test_unproject_kernel_paths_agree(side, views):
     """The tile kernel (C = 32, voxels % 128 == 0) and the generic kernel on the same maps.  A 9 m cuboid has
     tiles with voxels outside every map; at 30 m whole tiles see no view at all."""
     case = synth.volumetric_case(21, 2, views, volume_size=32, cuboid_side=side, with_volumes=False)
     feats, proj, coord, vconf = (to_dev(case[k]) for k in ("features", "proj", "coord_volumes", "vol_confidences"))
     for method in ("sum", "conf", "max", "softmax"):
-        outs = {}
-        for path in ("tile", "generic"):
-            monkeypatch.setenv("MVX_UNPROJ_PATH", path)
-            outs[path] = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+        outs = {"tile": unproject_c_abi(feats, proj, coord, vconf, method),
+                "generic": unproject_c_abi(feats, proj, coord, vconf, method, misalign_output=True)}
+        assert torch.equal(outs["tile"], op.unproject_heatmaps(feats, proj, coord, method, vconf))
         assert torch.allclose(outs["tile"], outs["generic"], rtol=0, atol=2e-6)
         if method == "softmax":
             sub = np.arange(0, 32 ** 3, 97)
             ref = orc.unproject_heatmaps(case["features"], case["proj"], case["coord_volumes"], method,
                                          case["vol_confidences"], voxel_subset=sub)
-            got = outs["tile"].reshape(2, 32, -1)[:, :, sub].cpu().numpy()
-            assert np.abs(got - ref).max() < UNPROJ_TOL
+            for path in ("tile", "generic"):
+                got = outs[path].reshape(2, 32, -1)[:, :, sub].cpu().numpy()
+                assert np.abs(got - ref).max() < UNPROJ_TOL
     # grids the tile kernel does not take (voxel count not a multiple of 128) go to the generic kernel
-    monkeypatch.delenv("MVX_UNPROJ_PATH")
     cut = coord[:, :31, :, :15].contiguous()
     generic = op.unproject_heatmaps(feats, proj, cut, "softmax", vconf)
     full = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
@@ -304,6 +338,76 @@ def test_unproject_errors():
         op.unproject_heatmaps(f, p, c, "conf")     # confidences missing
     out = op.unproject_heatmaps(f[:0], p[:0], c[:0], "sum")
     assert out.shape == (0, 4, 2, 2, 2)
+
+
+def test_volumetric_path_at_the_benchmark_size():
+    """64 frames x 4 views x 32 channels into 64^3 (softmax) and the 3-D soft-argmax of 64 x 17 volumes: the size
+    of the volumetric benchmark configuration, where the unprojection works through the batch in rounds of frames
+    and the soft-argmax uses its long segments.  Frames from every part of the batch against the oracle (on a voxel
+    subset for the unprojection); every other frame through frame-permutation equivariance, bit for bit."""
+    frames = 64
+    case = synth.device_volumetric_case(77, frames, 4, dev())
+    feats, proj, coord, vconf, vols = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
+    checked = (0, 9, 31, 63)
+    sub = np.arange(5, 64 ** 3, 1499)
+    for method in ("softmax", "conf"):
+        out = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+        assert out.shape == (frames, 32, 64, 64, 64)
+        for f in checked:
+            ref = orc.unproject_heatmaps(feats[f:f + 1].cpu().numpy(), proj[f:f + 1].cpu().numpy(),
+                                         coord[f:f + 1].cpu().numpy(), method, vconf[f:f + 1].cpu().numpy(), voxel_subset=sub)
+            got = out[f].reshape(32, -1)[:, torch.from_numpy(sub).to(dev())].cpu().numpy()
+            assert np.abs(got - ref[0]).max() < UNPROJ_TOL, (method, f)
+        perm = torch.randperm(frames, generator=torch.Generator().manual_seed(3)).to(dev())
+        out_p = op.unproject_heatmaps(feats[perm].contiguous(), proj[perm].contiguous(), coord[perm].contiguous(),
+                                      method, vconf[perm].contiguous())
+        for f in range(frames):       # frame by frame: a full-tensor gather would double the 2 GB
+            assert torch.equal(out_p[f], out[perm[f]]), (method, f)
+        del out_p
+        if method == "softmax":
+            # sampled in place from channel-last maps: same values through the other entry point
+            fcl = feats.view(frames * 4, 32, 96, 96).contiguous(memory_format=torch.channels_last).view(frames, 4, 32, 96, 96)
+            assert op._is_channels_last(fcl)
+            assert torch.equal(op.unproject_heatmaps(fcl, proj, coord, method, vconf), out)
+        del out
+    kp, vol_n = op.integrate_tensor_3d_with_coordinates(vols, coord)
+    for f in checked:
+        okp, ovol = orc.integrate_tensor_3d_with_coordinates(vols[f:f + 1].cpu().numpy(), coord[f:f + 1].cpu().numpy())
+        assert np.abs(kp[f].cpu().numpy() - okp[0]).max() <= MM_TOL, f
+        np.testing.assert_allclose(vol_n[f].cpu().numpy(), ovol[0], rtol=2e-5, atol=1e-30)
+    kp_p, vol_p = op.integrate_tensor_3d_with_coordinates(vols[perm].contiguous(), coord[perm].contiguous())
+    assert torch.equal(kp_p, kp[perm])
+    for f in range(frames):
+        assert torch.equal(vol_p[f], vol_n[perm[f]]), f
+    # each normalised volume sums to one
+    assert torch.allclose(vol_n.view(frames, 17, -1).sum(-1, dtype=torch.float64),
+                          torch.ones(frames, 17, dtype=torch.float64, device=dev()), rtol=0, atol=1e-5)
+
+
+def test_ops_refuse_to_drop_a_gradient():
+    """The kernels are forward-only.  An input that requires grad while autograd is recording would silently lose
+    its gradient (the reference's torch ops are differentiable), so the functions raise instead; under no_grad, or
+    for detached inputs, they run."""
+    case = synth.volumetric_case(5, 1, 2, n_joints=3, volume_size=8, with_volumes=True)
+    f, p, c, v = (to_dev(case[k]) for k in ("features", "proj", "coord_volumes", "volumes"))
+    hm = torch.randn(2, 3, 8, 8, device=dev())
+    for t in (f, v, hm):
+        t.requires_grad_(True)
+    with pytest.raises(_cabi.MvxError, match="forward-only"):
+        op.unproject_heatmaps(f, p, c, "sum")
+    with pytest.raises(_cabi.MvxError, match="forward-only"):
+        op.integrate_tensor_3d_with_coordinates(v, c)
+    with pytest.raises(_cabi.MvxError, match="forward-only"):
+        op.integrate_tensor_3d(v)
+    with pytest.raises(_cabi.MvxError, match="forward-only"):
+        op.integrate_tensor_2d(hm)
+    with torch.no_grad():
+        a = op.unproject_heatmaps(f, p, c, "sum")
+        b, _ = op.integrate_tensor_3d_with_coordinates(v, c)
+        k, _ = op.integrate_tensor_2d(hm)
+    assert torch.equal(a, op.unproject_heatmaps(f.detach(), p, c, "sum")) and not a.requires_grad
+    assert torch.equal(b, op.integrate_tensor_3d_with_coordinates(v.detach(), c)[0])
+    assert torch.equal(k, op.integrate_tensor_2d(hm.detach())[0])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -368,6 +472,19 @@ def test_soft_argmax_3d_shift_invariance_and_edges():
     assert np.abs(c1.cpu().numpy() - oc).max() <= MM_TOL
     c2, _ = op.integrate_tensor_3d_with_coordinates(to_dev(vols + np.float32(8.0)), to_dev(coord))
     assert torch.allclose(c1, c2, rtol=0, atol=1e-3)
+    # a NaN voxel makes that volume's keypoint NaN with and without the softmax, and only that one
+    for shape in ((2, 3, 10, 9, 7), (1, 2, 16, 16, 16)):
+        v0 = torch.randn(shape, device=dev())
+        cd = torch.randn(shape[:1] + shape[2:] + (3,), device=dev())
+        v1 = v0.clone()
+        v1[0, 1, 3, 2, 1] = float("nan")
+        for softmax in (True, False):
+            k0, p0 = op.integrate_tensor_3d_with_coordinates(v0, cd, softmax)
+            k1, p1 = op.integrate_tensor_3d_with_coordinates(v1, cd, softmax)
+            assert torch.isnan(k1[0, 1]).all() and torch.isnan(p1[0, 1, 3, 2, 1])
+            keep = torch.ones(shape[:2], dtype=torch.bool, device=dev())
+            keep[0, 1] = False
+            assert torch.equal(k1[keep], k0[keep]) and torch.equal(p1[keep], p0[keep])
     e = op.integrate_tensor_3d_with_coordinates(torch.zeros(0, 17, 4, 4, 4, device=dev()), torch.zeros(0, 4, 4, 4, 3, device=dev()))
     assert e[0].shape == (0, 17, 3)
     with pytest.raises(ValueError):

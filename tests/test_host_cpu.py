@@ -234,6 +234,43 @@ def test_bench_refuses_a_gpu_count_it_cannot_deliver():
     assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and r.stdout == ""
 
 
+def test_wrappers_refuse_tensors_on_different_devices(monkeypatch):
+    """Every wrapper checks that its tensors share one device before it takes raw pointers.  Driven on the CPU
+    with the float32 / HIP check switched off and tensors on the `meta` and `cpu` devices."""
+    from poseestimation_amd import _cabi
+    from poseestimation_amd.mvn.models import triangulation as tri
+    from poseestimation_amd.mvn.utils import op
+    a = torch.empty(1, device="meta")
+    _cabi.same_device(a, "a", b=torch.empty(2, device="meta"), c=None)
+    with pytest.raises(_cabi.MvxError, match="b is on cpu but a is on meta"):
+        _cabi.same_device(a, "a", b=torch.empty(2))
+    assert issubclass(_cabi.MvxError, RuntimeError)      # what torch raises for mixed devices
+
+    monkeypatch.setattr(_cabi, "device_f32", lambda t, name: t)
+    monkeypatch.setattr(_cabi, "load", lambda: pytest.fail("a kernel was reached with tensors on different devices"))
+    meta = lambda *shape: torch.empty(shape, device="meta")   # noqa: E731
+    cpu = lambda *shape: torch.empty(shape)                   # noqa: E731
+    with pytest.raises(_cabi.MvxError, match="proj_matricies is on cpu"):
+        op.unproject_heatmaps(meta(1, 2, 4, 8, 8), cpu(1, 2, 3, 4), meta(1, 2, 2, 2, 3), "sum")
+    with pytest.raises(_cabi.MvxError, match="coord_volumes is on cpu"):
+        op.unproject_heatmaps(meta(1, 2, 4, 8, 8), meta(1, 2, 3, 4), cpu(1, 2, 2, 2, 3), "sum")
+    with pytest.raises(_cabi.MvxError, match="vol_confidences is on cpu"):
+        op.unproject_heatmaps(meta(1, 2, 4, 8, 8), meta(1, 2, 3, 4), meta(1, 2, 2, 2, 3), "conf", cpu(1, 2, 4))
+    with pytest.raises(_cabi.MvxError, match="coord_volumes is on cpu"):
+        op.integrate_tensor_3d_with_coordinates(meta(1, 3, 2, 2, 2), cpu(1, 2, 2, 2, 3))
+    with pytest.raises(_cabi.MvxError, match="proj_matricies is on cpu"):
+        multiview.triangulate_batch_of_points(cpu(2, 4, 3, 4), meta(2, 4, 17, 2))
+    with pytest.raises(_cabi.MvxError, match="confidences is on cpu"):
+        multiview.triangulate_batch_of_points(meta(2, 4, 3, 4), meta(2, 4, 17, 2), cpu(2, 4, 17))
+    net = tri.AlgebraicTriangulationNet.__new__(tri.AlgebraicTriangulationNet)
+    torch.nn.Module.__init__(net)
+    net.use_confidences, net.heatmap_softmax, net.heatmap_multiplier = True, True, 100.0
+    with pytest.raises(_cabi.MvxError, match="proj_matricies is on cpu"):
+        net.triangulate_from_heatmaps(meta(1, 4, 17, 8, 8), meta(1, 4, 17), cpu(1, 4, 3, 4), (32, 32))
+    with pytest.raises(_cabi.MvxError, match="alg_confidences is on cpu"):
+        net.triangulate_from_heatmaps(meta(1, 4, 17, 8, 8), cpu(1, 4, 17), meta(1, 4, 3, 4), (32, 32))
+
+
 def test_heatmap_projections_match_the_camera_loop():
     """The vectorised camera rescale + projection of the volumetric forward against the per-camera
     update_after_resize / projection it replaces; the caller's cameras stay untouched."""
