@@ -232,13 +232,17 @@ int mvx_unity_points(const float* points, const int32_t* joint_order, int64_t n_
                      float* out, void* stream);
 
 /*
- * The per-frame tail of the real-time pipelines in one launch: replaces real_pipeline_trt.py:360-396 for a
- * full window.  frames holds the last n_steps poses; they are smoothed as by mvx_savgol_filter, and out[0] is
- * the mean of the last two smoothed poses, out[1] the last smoothed pose, both mapped as by mvx_unity_points.
- * frames  [n_steps][n_joints][3];  out  [2][n_joints][3]
+ * The per-frame tail of the real-time pipelines in one launch: replaces real_pipeline_trt.py:349-396 for one
+ * frame.  `ring` keeps the last n_steps poses on the device as a ring of slots; the call stores new_pose in slot
+ * ring_pos (the caller advances ring_pos = (ring_pos + 1) % n_steps per frame), so time runs over slots
+ * ring_pos + 1, ..., ring_pos (mod n_steps).
+ *   filtered == 0 (the pipeline's first slide_window_size frames): out[0] = new_pose mapped as by mvx_unity_points.
+ *   filtered != 0: the n_steps poses are smoothed as by mvx_savgol_filter; out[0] is the mean of the last two
+ *   smoothed poses, out[1] the last smoothed pose, both mapped as by mvx_unity_points.
+ * ring  [n_steps][n_joints][3] (read and written);  new_pose  [n_joints][3];  out  [2][n_joints][3]
  */
-int mvx_realtime_tail(const float* frames, int n_steps, int n_joints, const double* hat, int window,
-                      const int32_t* joint_order, float scale, float* out, void* stream);
+int mvx_realtime_tail(float* ring, const float* new_pose, int ring_pos, int n_steps, int n_joints, const double* hat,
+                      int window, const int32_t* joint_order, float scale, int filtered, float* out, void* stream);
 
 /*
  * HOST function (no device work): fills view_pairs with the sorted pairs that n_draws successive calls of

@@ -348,13 +348,67 @@ def gen_savgol():
     save("savgol", **out)
 
 
+def _reference_script_lines(path, first, last):
+    """Lines first..last (1-based, inclusive) of a reference script, read where it lies, dedented."""
+    import textwrap
+    with open(path) as f:
+        lines = f.readlines()
+    return textwrap.dedent("".join(lines[first - 1:last]))
+
+
+def gen_wire():
+    """Runs the reference's own per-frame tail -- the block of real_pipeline_trt.py that appends the new pose,
+    filters the last eight, maps joints and axes, scales and builds the message (lines 349-399; the joint names of
+    lines 133-135 and the joint order of line 472) -- on a walk of injected poses, and stores the messages it hands
+    to its sender.  The script cannot be imported (it opens cameras and TensorRT engines at import), so that block
+    is compiled from the file where it lies and executed frame by frame in a namespace that supplies what the
+    lines around it define: the pose of the frame, the reference's SAVGOLFilter, args.slide_window_size = 8 (its
+    default, :84) and a recorder in place of the socket sender.  Only the resulting numbers are kept."""
+    import types
+    sys.path.insert(0, REFERENCE)
+    from savgol_filer import SAVGOLFilter   # the reference's module (its file name)
+    script = os.path.join(REFERENCE, "real_pipeline_trt.py")
+    names_src = _reference_script_lines(script, 133, 135)
+    order_src = _reference_script_lines(script, 472, 472)
+    body = compile(_reference_script_lines(script, 349, 399), "real_pipeline_trt.py:349-399", "exec")
+    assert names_src.lstrip().startswith("kpt_s = [") and order_src.lstrip().startswith("point_change = [")
+
+    class Recorder:
+        def __init__(self):
+            self.saved = []
+
+        def save(self, kpts):
+            self.saved.append(kpts)
+
+    msg = Recorder()
+    ns = {"np": np, "torch": torch, "msg": msg, "args": types.SimpleNamespace(slide_window_size=8),
+          "filter_model": SAVGOLFilter(window_size=8), "frame_num": 0}
+    exec(names_src, ns)
+    exec(order_src, ns)
+    walk = gc.wire_input()
+    counts = []
+    for pose in walk:
+        ns["keypoints_3d_pred"] = torch.from_numpy(pose[None].copy())   # (1, 17, 3), as the model returns it
+        before = len(msg.saved)
+        exec(body, ns)
+        counts.append(len(msg.saved) - before)
+    names = list(ns["kpt_s"])
+    assert all(list(m) == names for m in msg.saved)
+    assert all(isinstance(v, float) for m in msg.saved for xyz in m.values() for v in xyz)
+    save("wire", input_sha=gc.sha(walk), names=np.array(names), point_change=np.array(ns["point_change"]),
+         counts=np.array(counts), messages=np.array([[m[n] for n in names] for m in msg.saved], dtype=np.float64),
+         frame_num_after=np.array(ns["frame_num"]), json_first=np.array(json.dumps(msg.saved[0])),
+         json_last=np.array(json.dumps(msg.saved[-1])))
+
+
 if __name__ == "__main__":
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
-    if len(sys.argv) > 1:                     # regenerate selected fixtures only: ransac, datasets, savgol
+    if len(sys.argv) > 1:                     # regenerate selected fixtures only: ransac, datasets, savgol, wire
         for name in sys.argv[1:]:
-            {"ransac": gen_ransac, "datasets": gen_datasets, "savgol": gen_savgol}[name]()
+            {"ransac": gen_ransac, "datasets": gen_datasets, "savgol": gen_savgol, "wire": gen_wire}[name]()
         sys.exit(0)
+    gen_wire()
     gen_ransac()
     gen_datasets()
     gen_savgol()

@@ -124,3 +124,15 @@ def savgol_input(i):
     rng = np.random.default_rng(1270 + i)
     walk = np.cumsum(rng.standard_normal((T, 17, 3)) * 15.0, axis=0) + rng.uniform(-800, 800, (1, 17, 3))
     return walk.astype(np.float32)
+
+
+# ---- wire format of the real-time pipelines ---------------------------------------------------------------------
+WIRE_FRAMES = 14
+
+
+def wire_input(seed=1290, n_frames=WIRE_FRAMES):
+    """(T, 17, 3) float32 random walk of poses in millimetres: what the model hands the pipeline frame by frame."""
+    rng = np.random.default_rng(seed)
+    walk = np.cumsum(rng.standard_normal((n_frames, 17, 3)) * 12.0, axis=0) + rng.uniform(-700, 700, (1, 17, 3))
+    return walk.astype(np.float32)
+

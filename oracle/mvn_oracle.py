@@ -487,7 +487,8 @@ def savgol_smooth(x, window_size):
 
 # ----------------------------------------------------------------------------
 # wire format of the real-time pipelines      reference: real_pipeline_trt.py:357-399
-# (inline script code that cannot be imported: this restatement is NOT pinned by reference outputs)
+# (inline script code that cannot be imported; pinned by tests/golden/wire.npz, the messages that block produced
+# when oracle/gen_golden.py executed it, from the file where it lies, on injected poses)
 # ----------------------------------------------------------------------------
 UNITY_JOINTS = ('Hip', 'RightHip', 'RightKnee', 'RightAnkle', 'LeftHip', 'LeftKnee', 'LeftAnkle', 'Spine', 'Thorax',
                 'Neck', 'Head', 'LeftShoulder', 'LeftElbow', 'LeftWrist', 'RightShoulder', 'RightElbow', 'RightWrist')

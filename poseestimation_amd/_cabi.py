@@ -42,7 +42,7 @@ SIGNATURES = {
     "mvx_draw_view_pairs": (_int, [_vp, _vp, _int, _i64, _vp]),
     "mvx_savgol_filter": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp]),
     "mvx_unity_points": (_int, [_vp, _vp, _i64, _int, _f32, _vp, _vp]),
-    "mvx_realtime_tail": (_int, [_vp, _int, _int, _vp, _int, _vp, _f32, _vp, _vp]),
+    "mvx_realtime_tail": (_int, [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _f32, _int, _vp, _vp]),
 }
 
 _lib = None

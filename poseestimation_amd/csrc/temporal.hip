@@ -60,27 +60,48 @@ __global__ __launch_bounds__(256) void unity_points(const float* __restrict__ po
     out[idx] = unity_component(p[0], p[1], p[2], c, scale);
 }
 
-// The last two filtered frames of a window of frames [n_steps][J][3], the mean of the two first, both mapped
-// to the wire convention: out [2][J][3].
-__global__ __launch_bounds__(64) void realtime_tail(const float* __restrict__ frames, int n_steps, int J,
-                                                    const double* __restrict__ hat, int window,
-                                                    const int* __restrict__ order, float scale,
+// One frame of the real-time tail.  `ring` holds the last n_steps poses as a ring of slots [n_steps][J][3]; the new
+// pose goes into slot ring_pos (the oldest one), so that time runs t = 0 .. n_steps-1 over slots
+// (ring_pos + 1 + t) % n_steps.  filtered == 0: out[0] = the new pose in the wire convention.  Otherwise the window
+// is smoothed and out[0] = mean of the last two smoothed poses, out[1] = the last smoothed pose, both in the wire
+// convention.  Lanes read the newest step from new_pose itself, never from the slot other lanes are writing.
+__global__ __launch_bounds__(64) void realtime_tail(float* __restrict__ ring, const float* __restrict__ new_pose,
+                                                    int ring_pos, int n_steps, int J, const double* __restrict__ hat,
+                                                    int window, const int* __restrict__ order, float scale, int filtered,
                                                     float* __restrict__ out) {
     const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= J * 3) return;
     const int j = idx / 3, c = idx % 3;
     const int src = order[j];
+    const int n_series = J * 3;
+    const float mine = new_pose[idx];
+    if (!filtered) {
+        out[idx] = unity_component(new_pose[src * 3 + 0], new_pose[src * 3 + 1], new_pose[src * 3 + 2], c, scale);
+        ring[ring_pos * n_series + idx] = mine;
+        return;
+    }
+    // both outputs lie in the last window: rows window-1 and window-2 of the hat matrix applied to it
+    const double* h1 = hat + static_cast<size_t>(window - 1) * window;
+    const double* h2 = hat + static_cast<size_t>(window - 2) * window;
     float last[3], mid[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int64_t s = static_cast<int64_t>(src) * 3 + k;
-        const float y1 = savgol_at(frames, n_steps, static_cast<int64_t>(J) * 3, hat, window, n_steps - 1, s);
-        const float y2 = savgol_at(frames, n_steps, static_cast<int64_t>(J) * 3, hat, window, n_steps - 2, s);
+        const int s = src * 3 + k;
+        double a1 = 0.0, a2 = 0.0;
+        for (int i = 0; i < window; ++i) {
+            const int t = n_steps - window + i;
+            const int slot = (ring_pos + 1 + t) % n_steps;
+            const double x = static_cast<double>(t == n_steps - 1 ? new_pose[s] : ring[slot * n_series + s]);
+            a1 = fma(h1[i], x, a1);
+            a2 = fma(h2[i], x, a2);
+        }
+        const float y1 = static_cast<float>(a1), y2 = static_cast<float>(a2);
         last[k] = y1;
         mid[k] = (y1 + y2) / 2.0f;
     }
     out[idx] = unity_component(mid[0], mid[1], mid[2], c, scale);
-    out[J * 3 + idx] = unity_component(last[0], last[1], last[2], c, scale);
+    out[n_series + idx] = unity_component(last[0], last[1], last[2], c, scale);
+    ring[ring_pos * n_series + idx] = mine;
 }
 
 int check_window(const char* name, int64_t n_steps, int window) {
@@ -128,17 +149,23 @@ extern "C" int mvx_unity_points(const float* points, const int32_t* joint_order,
     return MVX_OK;
 }
 
-extern "C" int mvx_realtime_tail(const float* frames, int n_steps, int n_joints, const double* hat, int window,
-                                 const int32_t* joint_order, float scale, float* out, void* stream) {
+extern "C" int mvx_realtime_tail(float* ring, const float* new_pose, int ring_pos, int n_steps, int n_joints,
+                                 const double* hat, int window, const int32_t* joint_order, float scale, int filtered,
+                                 float* out, void* stream) {
     using namespace mvx;
-    MVX_REQUIRE(n_steps >= 2 && n_joints > 0, MVX_ERR_INVALID_ARGUMENT,
-                "mvx_realtime_tail: bad shape n_steps=%d (>= 2) n_joints=%d", n_steps, n_joints);
-    const int rc = check_window("mvx_realtime_tail", n_steps, window);
-    if (rc != MVX_OK) return rc;
-    MVX_REQUIRE(frames != nullptr && hat != nullptr && joint_order != nullptr && out != nullptr,
+    MVX_REQUIRE(n_steps >= 2 && n_joints > 0 && n_joints <= (1 << 20) && ring_pos >= 0 && ring_pos < n_steps,
+                MVX_ERR_INVALID_ARGUMENT, "mvx_realtime_tail: bad shape n_steps=%d (>= 2) n_joints=%d ring_pos=%d", n_steps,
+                n_joints, ring_pos);
+    if (filtered) {
+        const int rc = check_window("mvx_realtime_tail", n_steps, window);
+        if (rc != MVX_OK) return rc;
+        MVX_REQUIRE(window >= 2 && hat != nullptr, MVX_ERR_INVALID_ARGUMENT,
+                    "mvx_realtime_tail: the filtered tail needs a hat matrix and window >= 2 (got %d)", window);
+    }
+    MVX_REQUIRE(ring != nullptr && new_pose != nullptr && joint_order != nullptr && out != nullptr,
                 MVX_ERR_INVALID_ARGUMENT, "mvx_realtime_tail: null pointer");
     hipLaunchKernelGGL(realtime_tail, dim3((n_joints * 3 + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       frames, n_steps, n_joints, hat, window, joint_order, scale, out);
+                       ring, new_pose, ring_pos, n_steps, n_joints, hat, window, joint_order, scale, filtered, out);
     MVX_CHECK_LAUNCH("mvx_realtime_tail");
     return MVX_OK;
 }

@@ -1,7 +1,8 @@
 """The steps the real-time pipelines run on every frame after triangulation (reference:
 real_pipeline_trt.py:349-399, pipeline_video.py:399-411): keep the recent poses, smooth them, and turn the
-result into the messages sent to the renderer.  The poses stay on the device; one launch produces both frames
-of a message pair and one small copy brings them to the host.  Sockets and queues (send_msg.py) are not part of
+result into the messages sent to the renderer.  The poses stay on the device in a ring of slots; per frame one
+launch stores the new pose, smooths the window and maps both frames of a message pair, and one small copy brings
+them to the host.  Sockets and queues (send_msg.py) are not part of
 this module: `encode` returns the bytes the reference hands to its socket.
 """
 import json
@@ -49,38 +50,47 @@ class RealtimeTail:
         self.order = tuple(order)
         self.frames_seen = 0
         self.scale = None
-        self._ring = None          # (window_frames, J, 3) on the device, oldest first
+        self._ring = None          # (window_frames, J, 3) on the device: slot frames_seen % window_frames is the oldest
         self._order_t = None
+        self._out = None
+        self._hat = None
+        self._window = 1
 
     def _setup(self, pose):
         n_joints = pose.shape[0]
-        self._ring = torch.zeros((self.window_frames, n_joints, 3), dtype=torch.float32, device=pose.device)
-        self._order_t = torch.tensor(self.order, dtype=torch.int32, device=pose.device)
+        dev = pose.device
+        self._ring = torch.zeros((self.window_frames, n_joints, 3), dtype=torch.float32, device=dev)
+        self._order_t = torch.tensor(self.order, dtype=torch.int32, device=dev)
+        self._out = torch.empty((2, n_joints, 3), dtype=torch.float32, device=dev)
+        self._window, order = fit_window(self.slide_window_size, self.window_frames)
+        self._hat = hat_matrix(self._window, order, dev)
 
     def push(self, keypoints_3d):
+        """One launch (the pose enters the device ring, the window is smoothed, joints and axes are mapped and
+        scaled) and one copy of at most 2 x J x 3 floats to the host per frame."""
         pose = _cabi.device_f32(keypoints_3d, "keypoints_3d").reshape(-1, 3)
         if self._ring is None:
             self._setup(pose)
-        self._ring = torch.roll(self._ring, -1, 0)
-        self._ring[-1] = pose
-        self.frames_seen += 1
+        _cabi.same_device(self._ring, "the pose ring", keypoints_3d=pose)
         n_joints = pose.shape[0]
-        if self.scale is None:
-            first = unity_points(pose, 1.0, self.order).cpu().numpy()
-            self.scale = np.float32(self.unity_len) / np.float32(np.linalg.norm(first[2] - first[3]))
+        if n_joints != self._ring.shape[1]:
+            raise ValueError("pose has %d joints, the first frame had %d" % (n_joints, self._ring.shape[1]))
+        slot = self.frames_seen % self.window_frames
+        self.frames_seen += 1
         # the reference filters once its frame counter (= poses stored, the new one included) exceeds the window size
-        if self.frames_seen > self.slide_window_size and self.frames_seen >= self.window_frames:
-            window, order = fit_window(self.slide_window_size, self.window_frames)
-            hat = hat_matrix(window, order, pose.device)
-            out = torch.empty((2, n_joints, 3), dtype=torch.float32, device=pose.device)
-            with torch.cuda.device(pose.device):
-                st = _cabi.load().mvx_realtime_tail(_cabi.ptr(self._ring), self.window_frames, n_joints, _cabi.ptr(hat),
-                                                    window, _cabi.ptr(self._order_t), float(self.scale), _cabi.ptr(out),
-                                                    _cabi.stream(pose.device))
-            _cabi.check(st, "mvx_realtime_tail")
-            host = out.cpu().numpy()
-        else:
-            host = unity_points(pose, float(self.scale), self.order).cpu().numpy()[None]
+        filtered = self.frames_seen > self.slide_window_size and self.frames_seen >= self.window_frames
+        first = self.scale is None
+        with torch.cuda.device(pose.device):
+            st = _cabi.load().mvx_realtime_tail(
+                _cabi.ptr(self._ring), _cabi.ptr(pose), slot, self.window_frames, n_joints, _cabi.ptr(self._hat),
+                self._window, _cabi.ptr(self._order_t), 1.0 if first else float(self.scale), int(filtered),
+                _cabi.ptr(self._out), _cabi.stream(pose.device))
+        _cabi.check(st, "mvx_realtime_tail")
+        host = self._out.cpu().numpy() if filtered else self._out[:1].cpu().numpy()
+        if first:
+            # bone between wire joints 2 and 3 of the first frame; numpy float32 arithmetic as in the pipeline
+            self.scale = np.float32(self.unity_len) / np.float32(np.linalg.norm(host[0][2] - host[0][3]))
+            host = host * self.scale
         return [self.message(frame) for frame in host]
 
     def message(self, wire_points):

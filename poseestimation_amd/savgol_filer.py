@@ -4,6 +4,10 @@ smoothing itself on the mvx HIP kernel.
 The reference runs scipy.signal.savgol_filter on the host, coordinate by coordinate; here a (T, K, C) pose
 tensor is filtered in one launch.  numpy arrays and CPU tensors are uploaded, filtered on the current HIP
 device and returned in the type they came in, as the reference returns them; there is no host filter.
+
+Precision: the kernel reads float32 samples, sums each window in float64 and rounds the result once to float32.
+float64 input (which scipy filters in float64) is therefore rounded to float32 on the way in and comes back as
+float64 values that carry float32 precision: about 6e-8 relative, 2.5e-4 mm on coordinates of a few metres.
 """
 import time
 import warnings

@@ -130,6 +130,31 @@ def test_unity_restatement_shapes():
     assert abs(np.linalg.norm(np.array(msg["RightKnee"]) - np.array(msg["RightAnkle"])) - 0.43) < 1e-6
 
 
+def test_wire_restatement_matches_the_reference_pipeline():
+    """The oracle's restatement of the real-time tail against the messages of the reference's own block
+    (real_pipeline_trt.py:349-399 executed on injected poses by oracle/gen_golden.py wire)."""
+    g = load("wire")
+    walk = gc.wire_input()
+    assert gc.sha(walk) == str(g["input_sha"])
+    assert tuple(g["names"]) == orc.UNITY_JOINTS and tuple(g["point_change"]) == orc.UNITY_ORDER
+    scale = np.float32(orc.unity_scale(walk[0]))
+    want, counts = g["messages"], g["counts"]
+    assert list(counts) == [1] * 8 + [2] * (len(walk) - 8) and int(g["frame_num_after"]) == len(walk)
+    k = 0
+    for n in range(len(walk)):
+        frames = [walk[n]] if n < 8 else orc.realtime_window_frames(walk[n - 7:n + 1])
+        for f in frames:
+            msg = orc.unity_message(f, scale)
+            got = np.array([msg[name] for name in orc.UNITY_JOINTS])
+            if n < 8:
+                assert np.array_equal(got, want[k]), n
+            else:   # float64 filter rounded once here, float32 convolution there
+                assert np.abs(got - want[k]).max() <= 2.0 ** -10 * float(scale), n
+            k += 1
+    import json
+    assert json.dumps(orc.unity_message(walk[0], scale)) == str(g["json_first"])
+
+
 # ---- data-loader glue --------------------------------------------------------------------------------------------
 def test_collate_and_prepare_batch_match_reference():
     g = load("datasets")
@@ -170,6 +195,7 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     assert lib.mvx_savgol_filter(None, 8, 51, None, 6, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT   # even window
     assert lib.mvx_savgol_filter(None, 5, 51, None, 7, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT   # longer than T
     assert lib.mvx_savgol_filter(None, 0, 51, None, 7, None, None) == _cabi.MVX_OK
-    assert lib.mvx_realtime_tail(None, 1, 17, None, 1, None, 1.0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_realtime_tail(None, None, 0, 1, 17, None, 1, None, 1.0, 1, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert lib.mvx_realtime_tail(None, None, 8, 8, 17, None, 7, None, 1.0, 0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT   # ring_pos
     assert lib.mvx_unity_points(None, None, -1, 17, 1.0, None, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
     assert lib.mvx_draw_view_pairs(None, None, 4, 10, None) == _cabi.MVX_ERR_INVALID_ARGUMENT

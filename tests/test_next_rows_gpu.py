@@ -304,33 +304,56 @@ def test_savgol_reproduces_quadratics_at_size():
 
 
 # ---- wire format -------------------------------------------------------------------------------------------------
-def test_unity_points_and_realtime_tail_match_restatement():
-    rng = np.random.default_rng(12)
-    walk = (np.cumsum(rng.standard_normal((14, 17, 3)) * 12.0, axis=0) + rng.uniform(-700, 700, (1, 17, 3))).astype(np.float32)
-    scale = orc.unity_scale(walk[0])
-    got = unity_points(to_dev(walk), float(np.float32(scale))).cpu().numpy()
-    want = np.stack([orc.unity_points(f) * np.float32(scale) for f in walk])
-    assert np.array_equal(got, want)
+def test_realtime_tail_matches_the_reference_pipeline():
+    """RealtimeTail.push, mvx_unity_points and mvx_realtime_tail against the messages the reference's own per-frame
+    block (real_pipeline_trt.py:349-399, run on injected poses when the fixture was made) handed to its sender.
+    Unfiltered frames are float32 products on both sides: exact.  Filtered frames: the reference rounds scipy's
+    float32 convolution, the kernel rounds a float64 sum once (2^-11 mm on coordinates below 4096 mm), then both
+    scale in float32."""
+    g = load("wire")
+    walk = gc.wire_input()
+    assert gc.sha(walk) == str(g["input_sha"])
+    assert tuple(g["names"]) == UNITY_JOINTS and tuple(g["point_change"]) == POINT_CHANGE
+    want, counts = g["messages"], g["counts"]
     tail = RealtimeTail(slide_window_size=8)
-    for n, frame in enumerate(walk, start=1):
+    k = 0
+    for n, frame in enumerate(walk):
         msgs = tail.push(to_dev(frame))
-        if n <= 8:
-            assert len(msgs) == 1
-            want_frames = [walk[n - 1]]
-        else:
-            assert len(msgs) == 2
-            want_frames = orc.realtime_window_frames(walk[n - 8:n])
-        for msg, frame_want in zip(msgs, want_frames):
-            ref = orc.unity_message(frame_want, np.float32(scale))
+        assert len(msgs) == counts[n]
+        for msg in msgs:
             assert list(msg) == list(UNITY_JOINTS)
-            for name in UNITY_JOINTS:
-                assert all(isinstance(v, float) for v in msg[name])
-                # the filter's float64 sum is rounded once here; the restatement rounds the scipy-style result
-                assert np.allclose(msg[name], ref[name], rtol=0, atol=2e-7 * 4096 * float(scale))
-    assert abs(float(tail.scale) - float(scale)) < 1e-9
-    payload = RealtimeTail.encode(msgs[-1])
-    assert isinstance(payload, bytes) and payload.startswith(b'{"Hip": [')
-    assert POINT_CHANGE[0] == 6
+            assert all(isinstance(v, float) for xyz in msg.values() for v in xyz)
+            got = np.array([msg[name] for name in UNITY_JOINTS])
+            if counts[n] == 1:
+                assert np.array_equal(got, want[k]), n
+            else:
+                assert np.abs(got - want[k]).max() <= 2.0 ** -10 * float(tail.scale), n
+            k += 1
+    assert k == len(want)
+    # the bytes for the socket: json.dumps of the message, as send_msg.py:49-50 writes them
+    first = RealtimeTail(slide_window_size=8)
+    assert RealtimeTail.encode(first.push(to_dev(walk[0]))[0]) == str(g["json_first"]).encode("utf-8")
+    # the building blocks through the C ABI: joint order / axes / scale of a whole batch of frames ...
+    scale = float(tail.scale)
+    mapped = unity_points(to_dev(walk), scale).cpu().numpy()
+    assert np.array_equal(mapped[:8], want[:8])
+    # ... and the ring: pushing the same walk through a ring that has wrapped several times gives the same tail
+    tail2 = RealtimeTail(slide_window_size=8)
+    for frame in np.concatenate([walk[:3], walk]):
+        last = tail2.push(to_dev(frame))
+    tail3 = RealtimeTail(slide_window_size=8)
+    tail3.scale = tail2.scale
+    tail3.frames_seen = 5                      # another ring phase
+    tail3._setup(to_dev(walk[0]))
+    for frame in walk[-8:]:
+        other = tail3.push(to_dev(frame))
+    assert other == last
+    # a filtered frame against the savgol kernel + the mapping kernel run separately
+    sm = savgol_device(to_dev(walk[-8:]), 7, 2)
+    sep = unity_points(torch.stack([(sm[-1] + sm[-2]) / 2, sm[-1]]), scale).cpu().numpy()
+    assert np.array_equal(sep, np.array([[m[name] for name in UNITY_JOINTS] for m in msgs], dtype=np.float32))
+    with pytest.raises(ValueError):
+        tail.push(torch.zeros(5, 3, device=dev()))
 
 
 # ---- data-loader glue on the device -----------------------------------------------------------------------------
