@@ -44,6 +44,14 @@ int mvx_version(void);
 const char* mvx_last_error(void);
 
 /*
+ * Testing aid with no counterpart in the reference: several entry points choose between kernels that compute the
+ * same result (by shape and alignment).  A bit set here (process-wide, default 0) takes one kernel out of the
+ * choice, so that tests and A/B timings can run the same inputs through the others.
+ */
+#define MVX_SELECT_NO_UNPROJECT_BRICKS 1u /* mvx_unproject*: 8x8x8-voxel brick kernel (4 views x 32 channels) off */
+void mvx_set_kernel_selection(unsigned mask);
+
+/*
  * Soft-argmax of n_maps heatmaps of h x w.           Replaces mvn/utils/op.py:11-47 (integrate_tensor_2d),
  * with the caller's `heatmaps * multiplier` (mvn/models/triangulation.py:190) folded in: each element is
  * first rounded to float32(x * multiplier), exactly as the separate torch multiply does (pass 1.0f for none).

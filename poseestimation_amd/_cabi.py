@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmvx.so")
 
 MVX_OK, MVX_ERR_INVALID_ARGUMENT, MVX_ERR_HIP, MVX_ERR_WORKSPACE, MVX_ERR_UNSUPPORTED = range(5)
 AGG_SUM, AGG_CONF, AGG_MAX, AGG_SOFTMAX = range(4)
+SELECT_NO_UNPROJECT_BRICKS = 1
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i64, _int, _f32, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
@@ -22,6 +23,7 @@ _i64, _int, _f32, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctype
 SIGNATURES = {
     "mvx_version": (_int, []),
     "mvx_last_error": (ctypes.c_char_p, []),
+    "mvx_set_kernel_selection": (None, [ctypes.c_uint]),
     "mvx_soft_argmax_2d": (_int, [_vp, _i64, _int, _int, _f32, _int, _vp, _vp, _vp]),
     "mvx_triangulate_dlt": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
     "mvx_algebraic_glue_dlt": (_int, [_vp, _vp, _vp, _i64, _int, _int, _f32, _f32, _vp, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@ namespace mvx {
 
 // ---- host side: error reporting -------------------------------------------------------------
 void set_error(const char* fmt, ...);
+unsigned kernel_selection();  // mask set by mvx_set_kernel_selection (MVX_SELECT_* bits)
 
 #define MVX_REQUIRE(cond, code, ...)      \
     do {                                  \

@@ -1,5 +1,7 @@
-// Error reporting and version of the mvx C ABI.
+// Error reporting, version and the kernel-selection switch of the mvx C ABI.
 #include <stdarg.h>
+
+#include <atomic>
 
 #include "mvx_common.h"
 
@@ -16,7 +18,16 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+namespace {
+std::atomic<unsigned> g_kernel_selection{0};
+}
+unsigned kernel_selection() { return g_kernel_selection.load(std::memory_order_relaxed); }
+
 }  // namespace mvx
+
+extern "C" void mvx_set_kernel_selection(unsigned mask) {
+    mvx::g_kernel_selection.store(mask, std::memory_order_relaxed);
+}
 
 extern "C" int mvx_version(void) { return MVX_VERSION; }
 

@@ -27,6 +27,7 @@
 // could reach at about 0.9-1.1 ms.
 //
 // HBM traffic per frame: V*C*h*w*4 (features) + N*12 (coordinates) + C*N*4 (volume written).
+#include <limits.h>
 #include <stdlib.h>
 
 #include "mvx_common.h"
@@ -55,8 +56,15 @@ constexpr float kLn2 = 0.69314718055994530942f;
 // feature gradient would multiply).  1/z is v_rcp_f32 refined by two Newton steps in float64 (relative error
 // below 1e-15) instead of a float64 division.  A voxel with z <= 0 gets all-zero weights; `wscale`
 // multiplies the weights (log2 e for the softmax aggregation, which works in base 2).
-__device__ __forceinline__ Tap project_tap(const double* __restrict__ Pd, double X, double Y, double Z, int H, int W,
-                                           float wscale) {
+struct TapXY {
+    float w00, w01, w10, w11;  // as in Tap
+    int xb, yb;                // top-left pixel of the 2 x 2 taps, inside the map: 0 <= xb <= W-2, 0 <= yb <= H-2
+    int x0, y0;                // floor of the sampling position, clamped to [-2, W] x [-2, H]
+    bool behind;               // z <= 0: all weights are zero
+};
+
+__device__ __forceinline__ TapXY project_tap_xy(const double* __restrict__ Pd, double X, double Y, double Z, int H,
+                                                int W, float wscale) {
     const double u = fma(X, Pd[0], fma(Y, Pd[1], fma(Z, Pd[2], Pd[3])));
     const double v = fma(X, Pd[4], fma(Y, Pd[5], fma(Z, Pd[6], Pd[7])));
     const double z0 = fma(X, Pd[8], fma(Y, Pd[9], fma(Z, Pd[10], Pd[11])));
@@ -67,27 +75,45 @@ __device__ __forceinline__ Tap project_tap(const double* __restrict__ Pd, double
     rz = fma(rz, fma(-z, rz, 1.0), rz);
     const double ixd = u * rz, iyd = v * rz;
     const double x0d = floor(ixd), y0d = floor(iyd);
+    // the fractions are rounded to float32 once; the complementary weights are 1 - fraction in float32
     const float wx1 = static_cast<float>(ixd - x0d), wy1 = static_cast<float>(iyd - y0d);
-    const float wx0 = static_cast<float>((x0d + 1.0) - ixd), wy0 = static_cast<float>((y0d + 1.0) - iyd);
+    const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
     const float x0f = static_cast<float>(x0d), y0f = static_cast<float>(y0d);
-    // clamp before the conversion so that far-away or non-finite positions become "outside"
-    const int x0 = static_cast<int>(fminf(fmaxf(x0f, -2.0f), static_cast<float>(W)));
-    const int y0 = static_cast<int>(fminf(fmaxf(y0f, -2.0f), static_cast<float>(H)));
-    const bool finite = (x0f - x0f == 0.0f) && (y0f - y0f == 0.0f) && !behind;
-    const bool vx0 = finite && x0 >= 0 && x0 <= W - 1, vx1 = finite && x0 + 1 >= 0 && x0 + 1 <= W - 1;
-    const bool vy0 = finite && y0 >= 0 && y0 <= H - 1, vy1 = finite && y0 + 1 >= 0 && y0 + 1 <= H - 1;
-    const int xb = min(max(x0, 0), W - 2), yb = min(max(y0, 0), H - 2);
-    // column xb holds tap x0 (if x0 == xb) or tap x0+1 (if x0 + 1 == xb, i.e. x0 == -1); likewise xb+1
-    const float cxa = (vx0 && x0 == xb) ? wx0 : ((vx1 && x0 + 1 == xb) ? wx1 : 0.0f);
-    const float cxb = (vx1 && x0 == xb) ? wx1 : ((vx0 && x0 == xb + 1) ? wx0 : 0.0f);
-    const float cya = ((vy0 && y0 == yb) ? wy0 : ((vy1 && y0 + 1 == yb) ? wy1 : 0.0f)) * wscale;
-    const float cyb = ((vy1 && y0 == yb) ? wy1 : ((vy0 && y0 == yb + 1) ? wy0 : 0.0f)) * wscale;
-    Tap t;
+    // far-away or non-finite positions, and voxels behind the camera, become "outside" (-2)
+    const bool usable = (fabsf(x0f) < 1.0e6f) && (fabsf(y0f) < 1.0e6f) && !behind;
+    const int x0 = usable ? static_cast<int>(fminf(fmaxf(x0f, -2.0f), static_cast<float>(W))) : -2;
+    const int y0 = usable ? static_cast<int>(fminf(fmaxf(y0f, -2.0f), static_cast<float>(H))) : -2;
+    // The taps are columns x0 and x0 + 1 with weights wx0 and wx1, zero outside the map.  They are read as
+    // columns xb and xb + 1 with xb = clamp(x0, 0, W - 2): the same columns when x0 lies in [0, W - 2]; for
+    // x0 = -1 column xb = 0 is tap x0 + 1, for x0 = W - 1 column xb + 1 is tap x0.  Likewise for rows.
+    const bool in_x = static_cast<unsigned>(x0) <= static_cast<unsigned>(W - 2);
+    const bool in_y = static_cast<unsigned>(y0) <= static_cast<unsigned>(H - 2);
+    const float cxa = in_x ? wx0 : (x0 == -1 ? wx1 : 0.0f);
+    const float cxb = in_x ? wx1 : (x0 == W - 1 ? wx0 : 0.0f);
+    const float cya = (in_y ? wy0 : (y0 == -1 ? wy1 : 0.0f)) * wscale;
+    const float cyb = (in_y ? wy1 : (y0 == H - 1 ? wy0 : 0.0f)) * wscale;
+    TapXY t;
     t.w00 = cxa * cya;
     t.w01 = cxb * cya;
     t.w10 = cxa * cyb;
     t.w11 = cxb * cyb;
-    t.pixel = static_cast<unsigned>(yb * W + xb);
+    t.xb = min(max(x0, 0), W - 2);
+    t.yb = min(max(y0, 0), H - 2);
+    t.x0 = x0;
+    t.y0 = y0;
+    t.behind = behind;
+    return t;
+}
+
+__device__ __forceinline__ Tap project_tap(const double* __restrict__ Pd, double X, double Y, double Z, int H, int W,
+                                           float wscale) {
+    const TapXY x = project_tap_xy(Pd, X, Y, Z, H, W, wscale);
+    Tap t;
+    t.w00 = x.w00;
+    t.w01 = x.w01;
+    t.w10 = x.w10;
+    t.w11 = x.w11;
+    t.pixel = static_cast<unsigned>(x.yb * W + x.xb);
     return t;
 }
 
@@ -173,10 +199,63 @@ __device__ __forceinline__ void interpolate(const Taps4& t, const float4& w, flo
     val[2] = hi.x;
     val[3] = hi.y;
 }
+// the same, results left as two packed pairs (channels 0,1 and 2,3)
+__device__ __forceinline__ void interpolate_x2(const Taps4& t, const float4& w, float2v& lo, float2v& hi) {
+    const float2v w00 = {w.x, w.x}, w01 = {w.y, w.y}, w10 = {w.z, w.z}, w11 = {w.w, w.w};
+    lo = __builtin_elementwise_fma(
+        float2v{t.f11.x, t.f11.y}, w11,
+        __builtin_elementwise_fma(float2v{t.f10.x, t.f10.y}, w10,
+                                  __builtin_elementwise_fma(float2v{t.f01.x, t.f01.y}, w01, float2v{t.f00.x, t.f00.y} * w00)));
+    hi = __builtin_elementwise_fma(
+        float2v{t.f11.z, t.f11.w}, w11,
+        __builtin_elementwise_fma(float2v{t.f10.z, t.f10.w}, w10,
+                                  __builtin_elementwise_fma(float2v{t.f01.z, t.f01.w}, w01, float2v{t.f00.z, t.f00.w} * w00)));
+}
 __device__ __forceinline__ void sample4(const float* __restrict__ img, const Tap& t, int W, int Cp, int q,
                                         float (&val)[4]) {
     const Taps4 f = load_taps(img, t.pixel, W, Cp, q);
     interpolate(f, make_float4(t.w00, t.w01, t.w10, t.w11), val);
+}
+
+// Aggregation of exactly four views of one channel (the view softmax evaluated exactly: max, then exp2; sampled
+// values arrive multiplied by log2 e).  One definition, so that every kernel rounds alike.
+template <int AGG>
+__device__ __forceinline__ float combine_four(float v0, float v1, float v2, float v3, float c0, float c1, float c2,
+                                              float c3) {
+    if (AGG == MVX_AGG_SUM) return ((v0 + v1) + v2) + v3;
+    if (AGG == MVX_AGG_CONF) return fmaf(v3, c3, fmaf(v2, c2, fmaf(v1, c1, v0 * c0)));
+    if (AGG == MVX_AGG_MAX) return fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    const float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    const float e0 = __builtin_amdgcn_exp2f(v0 - m), e1 = __builtin_amdgcn_exp2f(v1 - m);
+    const float e2 = __builtin_amdgcn_exp2f(v2 - m), e3 = __builtin_amdgcn_exp2f(v3 - m);
+    const float den = (e0 + e1) + (e2 + e3);
+    const float num = fmaf(e3, v3, fmaf(e2, v2, fmaf(e1, v1, e0 * v0)));
+    return num * __builtin_amdgcn_rcpf(den) * kLn2;
+}
+
+// The same for two channels at a time in packed float32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two
+// IEEE operations per instruction, each half rounding exactly as the scalar instruction does), which halves the
+// instruction count of everything but the maxima, the exponentials and the reciprocal.
+template <int AGG>
+__device__ __forceinline__ float2v combine_four_x2(float2v v0, float2v v1, float2v v2, float2v v3, float2v c0,
+                                                   float2v c1, float2v c2, float2v c3) {
+    if (AGG == MVX_AGG_SUM) return ((v0 + v1) + v2) + v3;
+    if (AGG == MVX_AGG_CONF)
+        return __builtin_elementwise_fma(v3, c3, __builtin_elementwise_fma(v2, c2, __builtin_elementwise_fma(v1, c1, v0 * c0)));
+    float2v m;
+    m.x = fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3.x));
+    m.y = fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3.y));
+    if (AGG == MVX_AGG_MAX) return m;
+    const float2v d0 = v0 - m, d1 = v1 - m, d2 = v2 - m, d3 = v3 - m;
+    const float2v e0 = {__builtin_amdgcn_exp2f(d0.x), __builtin_amdgcn_exp2f(d0.y)};
+    const float2v e1 = {__builtin_amdgcn_exp2f(d1.x), __builtin_amdgcn_exp2f(d1.y)};
+    const float2v e2 = {__builtin_amdgcn_exp2f(d2.x), __builtin_amdgcn_exp2f(d2.y)};
+    const float2v e3 = {__builtin_amdgcn_exp2f(d3.x), __builtin_amdgcn_exp2f(d3.y)};
+    const float2v den = (e0 + e1) + (e2 + e3);
+    const float2v num = __builtin_elementwise_fma(e3, v3, __builtin_elementwise_fma(e2, v2, __builtin_elementwise_fma(e1, v1, e0 * v0)));
+    const float2v rden = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const float2v ln2 = {kLn2, kLn2};
+    return num * rden * ln2;
 }
 
 // [n][C][HW] -> [n][HW][Cp], Cp = C rounded up to 4 (pad = 0).  64-pixel x 32-channel tiles through LDS.
@@ -292,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
     const int q = tid & 7;
     const float* fb = feat_cl + b * V * img_stride;
     if (FOUR) {
-        float cc[4][4];
+        float cc[4][4] = {};
         if (AGG == MVX_AGG_CONF) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -319,21 +398,8 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
             for (int v = 0; v < 4; ++v) interpolate(f[v], w4[v], val[v]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float r;
-                if (AGG == MVX_AGG_SUM) {
-                    r = ((val[0][k] + val[1][k]) + val[2][k]) + val[3][k];
-                } else if (AGG == MVX_AGG_CONF) {
-                    r = fmaf(val[3][k], cc[3][k], fmaf(val[2][k], cc[2][k], fmaf(val[1][k], cc[1][k], val[0][k] * cc[0][k])));
-                } else if (AGG == MVX_AGG_MAX) {
-                    r = fmaxf(fmaxf(val[0][k], val[1][k]), fmaxf(val[2][k], val[3][k]));
-                } else {
-                    const float m = fmaxf(fmaxf(val[0][k], val[1][k]), fmaxf(val[2][k], val[3][k]));
-                    const float e0 = __builtin_amdgcn_exp2f(val[0][k] - m), e1 = __builtin_amdgcn_exp2f(val[1][k] - m);
-                    const float e2 = __builtin_amdgcn_exp2f(val[2][k] - m), e3 = __builtin_amdgcn_exp2f(val[3][k] - m);
-                    const float den = (e0 + e1) + (e2 + e3);
-                    const float num = fmaf(e3, val[3][k], fmaf(e2, val[2][k], fmaf(e1, val[1][k], e0 * val[0][k])));
-                    r = num * __builtin_amdgcn_rcpf(den) * kLn2;
-                }
+                const float r = combine_four<AGG>(val[0][k], val[1][k], val[2][k], val[3][k], cc[0][k], cc[1][k],
+                                                  cc[2][k], cc[3][k]);
                 out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = r;
             }
         }
@@ -375,6 +441,392 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
         const int c = flat / (kTile / 4), grp = flat % (kTile / 4);
         const float4 r = *reinterpret_cast<const float4*>(out_t + c * kTile + ((grp ^ ((c >> 2) & 7)) << 2));
         *reinterpret_cast<float4*>(vol + (b * C + c) * n_vox + n0 + grp * 4) = r;
+    }
+}
+
+
+// ---- brick kernel: C = 32, four views, grid dimensions multiples of 8 ------------------------------------------
+// A workgroup of 512 threads owns a brick of 8 x 8 x 8 voxels, one voxel per lane.  Neighbouring voxels sample
+// neighbouring pixels, so the taps of a brick lie in a small patch of each view's map (about 13 x 12 pixels for the
+// camera set-up of the reference: one voxel is about one heatmap pixel); the patch is copied once into LDS and the
+// 2 x 2 x 32-channel taps are read from there: 512 bytes per voxel and view come out of LDS (256 B/clk per CU)
+// instead of the vector L1 (46 B/clk for this access shape), and about 13 times fewer bytes cross the L1.
+//   1. every lane projects its voxel into the four views (weights and tap pixel stay in its registers);
+//   2. the bounding box of the taps is taken from the brick's 8 corner voxels (exact for any grid whose voxel
+//      positions are affine in the voxel index and in front of the camera: the projection of a convex set is
+//      convex); every lane then checks its own taps against the box, so for anything else -- arbitrary coordinate
+//      tensors, a corner behind a camera, a patch larger than 16 x 16 pixels -- the whole brick takes the direct
+//      path (taps from global memory, same arithmetic);
+//   3. two passes of two views: the patches (rows of 16 pixels x 128 bytes) are copied global -> LDS by
+//      global_load_lds_dwordx4 (no registers, no VALU beyond the source address), the 16-byte channel quad q of a
+//      pixel in patch row py sits at position q ^ (py & 7) of the pixel's 128 bytes, so that the lanes of a wave --
+//      which read the same quad of pixels in different rows -- hit different banks;
+//   4. per channel quad a lane reads its taps with ds_read_b128 (the two taps of a row share one address, the
+//      second at +128 bytes), interpolates (packed FMA) and, in the second pass, aggregates the four views and
+//      stores: a wave's store of one channel covers 8 runs of 8 voxels (32 bytes each); bricks adjacent along z
+//      run back to back on one XCD and complete the 128-byte lines in its L2.
+// The lane -> voxel map puts the 16 lanes that one ds_read_b128 cycle serves (lanes whose 4-lane chunks have an even,
+// respectively odd, number of set bits in the chunk index) on 2 (y) x 8 (z) voxels, i.e. on a column of pixels.
+constexpr int kBrick = 8;
+constexpr int kBrickThreads = 512;
+constexpr int kPatchW = 16;
+constexpr int kPatchRows = 16;
+constexpr int kPixelBytes = 128;
+constexpr int kPatchBytes = kPatchW * kPatchRows * kPixelBytes;  // 32 KB per view, two views resident
+
+struct BrickShared {
+    double cam[4 * 12];
+    int corner[4][2][8];  // floor position (x0, y0) of the 8 corner voxels per view; INT_MAX for a corner behind the camera
+    int bad;              // some lane's taps lie outside the patches
+};
+
+// Division of small non-negative numbers by a runtime constant without the float-reciprocal sequence the compiler
+// emits for it: q = (mulhi(n, magic) + n) >> shift, exact for n < 2^31 (magic and shift from fast_divisor()).
+struct FastDiv {
+    unsigned magic, shift, divisor;
+};
+inline FastDiv fast_divisor(unsigned d) {
+    FastDiv f;
+    f.divisor = d;
+    f.shift = 0;
+    while ((1u << f.shift) < d) ++f.shift;
+    f.magic = static_cast<unsigned>((((1ull << f.shift) - d) << 32) / d + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv f) { return (__umulhi(n, f.magic) + n) >> f.shift; }
+
+#ifdef MVX_BRICK_STATS  // development builds only (tools/brick_stats.hip)
+__device__ unsigned brick_stats[4];  // bricks, bricks on the direct path, bricks whose patches do not fit, max rows
+__device__ unsigned long long brick_phase[8];  // summed s_memtime deltas of wave 0 between the kernel's phases
+#define MVX_STAMP(i)                                                                    \
+    do {                                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                   \
+        if (tid == 0) atomicAdd(&brick_phase[i], now_ - stamp_);                        \
+        stamp_ = now_;                                                                  \
+    } while (0)
+#else
+#define MVX_STAMP(i)
+#endif
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef __attribute__((address_space(1))) const unsigned char global_byte;
+
+// The four taps of channel quad q read from a staged patch.  `base` = byte offset of pixel (rx, ry) in the patch,
+// k0 / k1 = (row & 7) << 4 of the tap rows ry and ry + 1.
+__device__ __forceinline__ Taps4 patch_taps(const unsigned char* __restrict__ patch, unsigned base, unsigned k0,
+                                            unsigned k1, int q) {
+    const unsigned char* p0 = patch + (base + (k0 ^ (static_cast<unsigned>(q) << 4)));
+    const unsigned char* p1 = patch + (base + (k1 ^ (static_cast<unsigned>(q) << 4)));
+    Taps4 t;
+    t.f00 = *reinterpret_cast<const float4*>(p0);
+    t.f01 = *reinterpret_cast<const float4*>(p0 + kPixelBytes);
+    t.f10 = *reinterpret_cast<const float4*>(p1 + kPatchW * kPixelBytes);
+    t.f11 = *reinterpret_cast<const float4*>(p1 + kPatchW * kPixelBytes + kPixelBytes);
+    return t;
+}
+
+// 4 x 4 transpose across the four lanes of a quad: lane i holds a[0..3] on entry and (lane 0's a[i], lane 1's a[i],
+// lane 2's a[i], lane 3's a[i]) on exit.  Two butterfly stages (lane ^ 1, then lane ^ 2), each a DPP quad
+// permutation and a select per register.
+__device__ __forceinline__ void quad_transpose(float (&a)[4], int lane) {
+    const bool odd = lane & 1, upper = lane & 2;
+    const float s0 = odd ? a[0] : a[1], s1 = odd ? a[2] : a[3];  // what the partner (lane ^ 1) needs
+    const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
+    if (odd) {
+        a[0] = r0;
+        a[2] = r1;
+    } else {
+        a[1] = r0;
+        a[3] = r1;
+    }
+    const float t0 = upper ? a[0] : a[2], t1 = upper ? a[1] : a[3];  // what the partner (lane ^ 2) needs
+    const float u0 = dpp_mov<0x4E>(t0), u1 = dpp_mov<0x4E>(t1);
+    if (upper) {
+        a[0] = u0;
+        a[1] = u1;
+    } else {
+        a[2] = u0;
+        a[3] = u1;
+    }
+}
+
+template <int AGG>
+__global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const float* __restrict__ feat_cl,
+                                                                       const float* __restrict__ proj,
+                                                                       const float* __restrict__ coord,
+                                                                       const float* __restrict__ vconf, int H, int W,
+                                                                       int vx, int vy, int vz, FastDiv bricks_per_frame,
+                                                                       FastDiv nbz, FastDiv nby, double sx, double sy,
+                                                                       float* __restrict__ vol) {
+    constexpr int C = 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    BrickShared* sh = reinterpret_cast<BrickShared*>(smem + 2 * kPatchBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned frame = fast_div(work, bricks_per_frame);
+    const int64_t b = frame;
+    const unsigned brick = work - frame * bricks_per_frame.divisor;
+    const unsigned brick_xy = fast_div(brick, nbz);
+    const int bz = static_cast<int>(brick - brick_xy * nbz.divisor);
+    const int bx = static_cast<int>(fast_div(brick_xy, nby));
+    const int by = static_cast<int>(brick_xy - static_cast<unsigned>(bx) * nby.divisor);
+    // lane -> voxel of the brick
+    const int chunk = (lane >> 2) & 7;
+    const int grp = ((lane >> 5) << 1) | (__builtin_popcount(chunk) & 1);
+    const int idx = ((chunk >> 1) << 2) | (lane & 3);
+    const int lx = wave, ly = (grp << 1) | (idx >> 3), lz = idx & 7;
+    const int64_t n_vox = static_cast<int64_t>(vx) * vy * vz;
+    const int64_t n = (static_cast<int64_t>(bx * kBrick + lx) * vy + by * kBrick + ly) * vz + bz * kBrick + lz;
+    const size_t img_stride = static_cast<size_t>(H) * W * C;
+    const float* fb = feat_cl + b * 4 * img_stride;
+
+#ifdef MVX_BRICK_STATS
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+    if (tid < 48) sh->cam[tid] = camera_entry(proj + b * 48 + (tid / 12) * 12, tid % 12, sx, sy);
+    if (tid == 64) sh->bad = 0;
+    __syncthreads();
+
+    // 1./2. projection, patch rectangles and per-lane check, a pair of views at a time: the patches of views 0 and 1
+    // are on their way into LDS while views 2 and 3 are projected.
+    const float* cp = coord + (b * n_vox + n) * 3;
+    const double X = cp[0], Y = cp[1], Z = cp[2];
+    float4 wt[4];
+    int txb[4], tyb[4];
+    int ox[4], oy[4], rows[4];
+    unsigned base[4], k0[4], k1[4];
+    bool fits = true, inside = true;
+    const bool corner = (lx == 0 || lx == kBrick - 1) && (ly == 0 || ly == kBrick - 1) && (lz == 0 || lz == kBrick - 1);
+    const int corner_id = ((lx & 4) | (ly & 2) | (lz & 1));  // for lx, ly, lz in {0, 7}
+
+    // projects the two views of a pass; the corner voxels leave their floor positions for everybody
+    auto project_pair = [&](int pass) {
+#pragma unroll
+        for (int vv = 0; vv < 2; ++vv) {
+            const int v = pass * 2 + vv;
+            const TapXY t = project_tap_xy(sh->cam + v * 12, X, Y, Z, H, W, AGG == MVX_AGG_SOFTMAX ? kLog2e : 1.0f);
+            wt[v] = make_float4(t.w00, t.w01, t.w10, t.w11);
+            txb[v] = t.xb;
+            tyb[v] = t.yb;
+            if (corner) {
+                sh->corner[v][0][corner_id] = t.behind ? INT_MAX : t.x0;
+                sh->corner[v][1][corner_id] = t.y0;
+            }
+        }
+    };
+    // patch rectangles of the two views (wave-uniform): minimum and maximum over each group of 8 lanes holding the
+    // 8 corners of one (view, axis); then the per-lane check and the tap addresses
+    auto rectangles_pair = [&](int pass) {
+        int cmin = reinterpret_cast<const int*>(sh->corner)[pass * 32 + (lane & 31)], cmax = cmin;
+        cmin = min(cmin, dpp_movi<0xB1>(cmin));
+        cmax = max(cmax, dpp_movi<0xB1>(cmax));
+        cmin = min(cmin, dpp_movi<0x4E>(cmin));
+        cmax = max(cmax, dpp_movi<0x4E>(cmax));
+        cmin = min(cmin, dpp_movi<0x141>(cmin));
+        cmax = max(cmax, dpp_movi<0x141>(cmax));
+#pragma unroll
+        for (int vv = 0; vv < 2; ++vv) {
+            const int v = pass * 2 + vv;
+            const int minx = __builtin_amdgcn_readlane(cmin, vv * 16), miny = __builtin_amdgcn_readlane(cmin, vv * 16 + 8);
+            const int maxx = __builtin_amdgcn_readlane(cmax, vv * 16), maxy = __builtin_amdgcn_readlane(cmax, vv * 16 + 8);
+            ox[v] = min(max(minx, 0), W - 2);
+            oy[v] = min(max(miny, 0), H - 2);
+            const int ex = min(max(maxx, 0), W - 2) + 1, ey = min(max(maxy, 0), H - 2) + 1;  // last column / row read
+            rows[v] = ey - oy[v] + 1;
+            // a corner behind the camera reads as INT_MAX: no patch
+            fits = fits && (maxx != INT_MAX) && (ex - ox[v] + 1 <= kPatchW) && (rows[v] <= kPatchRows);
+            const unsigned any = __builtin_bit_cast(unsigned, wt[v].x) | __builtin_bit_cast(unsigned, wt[v].y) |
+                                 __builtin_bit_cast(unsigned, wt[v].z) | __builtin_bit_cast(unsigned, wt[v].w);
+            // voxels whose weights are all zero read the patch origin (always staged) instead of wherever the clamp went
+            const int rx = any ? txb[v] - ox[v] : 0, ry = any ? tyb[v] - oy[v] : 0;
+            inside = inside && rx >= 0 && rx + 1 < kPatchW && ry >= 0 && ry + 1 < rows[v];
+            base[v] = static_cast<unsigned>(ry * kPatchW + rx) * kPixelBytes;
+            k0[v] = static_cast<unsigned>(ry & 7) << 4;
+            k1[v] = static_cast<unsigned>((ry + 1) & 7) << 4;
+        }
+    };
+    // starts the copies of the two patches of a pass: rows of 16 pixels, half a row per wave-instruction
+    auto stage_pair = [&](int pass) {
+#pragma unroll
+        for (int vv = 0; vv < 2; ++vv) {
+            const int v = pass * 2 + vv;
+            global_byte* img = (global_byte*)(fb + v * img_stride);
+            lds_byte* dst = (lds_byte*)(smem) + vv * kPatchBytes;
+#pragma unroll
+            for (int it = 0; it < kPatchRows / 4; ++it) {
+                const int py = it * 4 + (wave >> 1);  // wave-uniform
+                if (py < rows[v]) {
+                    const int px = ((wave & 1) << 3) + (lane >> 3);
+                    const int q = (lane & 7) ^ (py & 7);
+                    const int gx = min(ox[v] + px, W - 1), gy = oy[v] + py;
+                    const unsigned src = (static_cast<unsigned>(gy * W + gx) * C + static_cast<unsigned>(q) * 4u) * 4u;
+                    __builtin_amdgcn_global_load_lds(img + src, dst + (py * kPatchW + ((wave & 1) << 3)) * kPixelBytes,
+                                                     16, 0, 0);
+                }
+            }
+        }
+    };
+
+    project_pair(0);
+    MVX_STAMP(0);  // set-up + projection of views 0, 1
+    __syncthreads();
+    MVX_STAMP(1);  // wait at the barrier
+    rectangles_pair(0);
+    const bool fits01 = fits;
+    if (fits01) stage_pair(0);  // harmless if a lane turns out not to fit: the vote below decides who reads
+    MVX_STAMP(2);  // rectangles + copy issue (pass 0)
+    project_pair(1);
+    MVX_STAMP(3);  // projection of views 2, 3 (the copies are in flight)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    MVX_STAMP(4);  // wait for the copies
+    rectangles_pair(1);
+    if (!inside) sh->bad = 1;
+    __syncthreads();
+    const bool staged = fits && (sh->bad == 0);
+
+    // voxel of lane (lane & ~3), channel (lane & 3) of a quad: where this lane's 16-byte store of pass 1 starts
+    const int64_t quad_off = b * C * n_vox + (n - (lane & 3)) + static_cast<int64_t>(lane & 3) * n_vox;
+#ifdef MVX_BRICK_STATS  // development builds only (tools/brick_stats.hip): how many bricks leave the staged path, and why
+    if (tid == 0) {
+        atomicAdd(&brick_stats[0], 1u);
+        if (!staged) atomicAdd(&brick_stats[1], 1u);
+        if (!fits) atomicAdd(&brick_stats[2], 1u);
+        atomicMax(&brick_stats[3], static_cast<unsigned>(max(max(rows[0], rows[1]), max(rows[2], rows[3]))));
+    }
+#endif
+    if (!staged) {
+        // Direct path: taps from global memory with the tile kernel's access shape -- 8 lanes per voxel, each
+        // fetching its 16 bytes of whole 128-byte lines -- and the same arithmetic.  The weights and tap pixels
+        // change lanes through tables in the (unused) patch area; slots are ordered so that the 8 voxels of a step
+        // are consecutive along z.
+        float4* wts = reinterpret_cast<float4*>(smem);                                          // [4][512]
+        unsigned* pix = reinterpret_cast<unsigned*>(smem + 4 * kBrickThreads * sizeof(float4));  // [4][512]
+        unsigned* vox = pix + 4 * kBrickThreads;                                                // [512]
+        const int slot = wave * 64 + ly * kBrick + lz;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            wts[v * kBrickThreads + slot] = wt[v];
+            pix[v * kBrickThreads + slot] = static_cast<unsigned>(tyb[v] * W + txb[v]);
+        }
+        vox[slot] = static_cast<unsigned>(n);
+        __syncthreads();
+        const int q = lane & 7;
+        float cc[4][4] = {};
+        if (AGG == MVX_AGG_CONF) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * 4 + v) * C + q * 4);
+                cc[v][0] = c4.x;
+                cc[v][1] = c4.y;
+                cc[v][2] = c4.z;
+                cc[v][3] = c4.w;
+            }
+        }
+#pragma unroll 1
+        for (int step = 0; step < 8; ++step) {
+            const int t = wave * 64 + step * 8 + (lane >> 3);
+            float4 w4[4];
+            Taps4 f[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                w4[v] = wts[v * kBrickThreads + t];
+                f[v] = load_taps(fb + v * img_stride, pix[v * kBrickThreads + t], W, C, q);
+            }
+            float val[4][4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) interpolate(f[v], w4[v], val[v]);
+            float* dst = vol + b * C * n_vox + vox[t];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                dst[static_cast<int64_t>(q * 4 + k) * n_vox] = combine_four<AGG>(
+                    val[0][k], val[1][k], val[2][k], val[3][k], cc[0][k], cc[1][k], cc[2][k], cc[3][k]);
+        }
+        return;
+    }
+
+    // 3./4. two passes of two views
+    // what pass 1 leaves for pass 2: both views' values for the softmax, their partial aggregate otherwise
+    constexpr int kKeep = (AGG == MVX_AGG_SOFTMAX) ? 2 : 1;
+    float2v keep[kKeep][C / 2];  // channel pairs
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            __syncthreads();  // every lane has read the patches of pass 0
+            stage_pair(1);
+            MVX_STAMP(5);  // barrier + copy issue (pass 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            MVX_STAMP(6);  // wait for the copies
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float2v val[2][2];  // [view of the pass][channel pair of the quad]
+#pragma unroll
+            for (int vv = 0; vv < 2; ++vv) {
+                const int v = pass * 2 + vv;
+                const Taps4 f = patch_taps(smem + vv * kPatchBytes, base[v], k0[v], k1[v], q);
+                interpolate_x2(f, wt[v], val[vv][0], val[vv][1]);
+            }
+            float2v cc[4][2] = {};
+            if (AGG == MVX_AGG_CONF) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float* cv = vconf + (b * 4 + v) * C + q * 4;
+                    cc[v][0] = float2v{cv[0], cv[1]};
+                    cc[v][1] = float2v{cv[2], cv[3]};
+                }
+            }
+            float res[4];  // the four channels of the quad (pass 1)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cp = q * 2 + h;  // channel pair
+                if (pass == 0) {
+                    if (AGG == MVX_AGG_SOFTMAX) {
+                        keep[0][cp] = val[0][h];
+                        keep[kKeep - 1][cp] = val[1][h];
+                    } else if (AGG == MVX_AGG_SUM) {
+                        keep[0][cp] = val[0][h] + val[1][h];
+                    } else if (AGG == MVX_AGG_CONF) {
+                        keep[0][cp] = __builtin_elementwise_fma(val[1][h], cc[1][h], val[0][h] * cc[0][h]);
+                    } else {
+                        keep[0][cp] = float2v{fmaxf(val[0][h].x, val[1][h].x), fmaxf(val[0][h].y, val[1][h].y)};
+                    }
+                    // pin the values here: left alone, the compiler sinks the interpolation into pass 2 and carries
+                    // the raw taps (four times as many registers) across the barrier instead
+                    asm volatile("" : "+v"(keep[0][cp]));
+                    if (kKeep == 2) asm volatile("" : "+v"(keep[kKeep - 1][cp]));
+                } else {
+                    float2v r;
+                    if (AGG == MVX_AGG_SOFTMAX) {
+                        const float2v z = {0.0f, 0.0f};
+                        r = combine_four_x2<AGG>(keep[0][cp], keep[kKeep - 1][cp], val[0][h], val[1][h], z, z, z, z);
+                    } else if (AGG == MVX_AGG_SUM) {
+                        r = (keep[0][cp] + val[0][h]) + val[1][h];
+                    } else if (AGG == MVX_AGG_CONF) {
+                        r = __builtin_elementwise_fma(val[1][h], cc[3][h], __builtin_elementwise_fma(val[0][h], cc[2][h], keep[0][cp]));
+                    } else {
+                        r = float2v{fmaxf(keep[0][cp].x, fmaxf(val[0][h].x, val[1][h].x)),
+                                    fmaxf(keep[0][cp].y, fmaxf(val[0][h].y, val[1][h].y))};
+                    }
+                    res[h * 2] = r.x;
+                    res[h * 2 + 1] = r.y;
+                }
+            }
+            if (pass == 1) {
+                // the four lanes of a quad hold four consecutive voxels along z: after the transpose each lane stores
+                // one channel of all four with a single 16-byte store
+                quad_transpose(res, lane);
+                *reinterpret_cast<float4*>(vol + quad_off + static_cast<int64_t>(q * 4) * n_vox) =
+                    make_float4(res[0], res[1], res[2], res[3]);
+            }
+            // keep the quads in order: hoisting the reads of later quads above this point would need hundreds of
+            // registers
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        MVX_STAMP(7);  // sampling (both passes)
     }
 }
 
@@ -449,6 +901,13 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
     const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
     const bool tiled = (C == 32) && (V <= kTileMaxViews) && (n_voxels % kTile == 0) && aligned16(volumes) &&
                        (aggregation != MVX_AGG_CONF || aligned16(vol_conf));
+    // the brick kernel: four views of 32 channels into a grid whose sides are multiples of 8 (the reference's
+    // 4-camera, 64^3 set-up); other shapes take the tile or the any-shape kernel
+    const bool bricked = (C == 32) && (V == 4) && (vx % kBrick == 0) && (vy % kBrick == 0) && (vz % kBrick == 0) &&
+                         (static_cast<int64_t>(h) * w * C * 4 < (1LL << 31)) && (n_voxels < (1LL << 32)) &&
+                         aligned16(volumes) &&
+                         (aggregation != MVX_AGG_CONF || aligned16(vol_conf)) &&
+                         !(kernel_selection() & MVX_SELECT_NO_UNPROJECT_BRICKS);
     const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V) * kTile * 20 + static_cast<size_t>(V) * 12 * 8;
     const double sx = static_cast<double>(w - 1) / static_cast<double>(h);  // ix = x / H * (W - 1)
     const double sy = static_cast<double>(h - 1) / static_cast<double>(w);  // iy = y / W * (H - 1)
@@ -471,7 +930,25 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
         const float* cd = coords + f0 * n_voxels * 3;
         const float* vc = vol_conf != nullptr ? vol_conf + f0 * V * C : nullptr;
         float* vo = volumes + f0 * C * n_voxels;
-        if (tiled) {
+        if (bricked) {
+            const int bricks = (vx / kBrick) * (vy / kBrick) * (vz / kBrick);
+            MVX_REQUIRE(nf * bricks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
+            const dim3 grid(static_cast<unsigned>(nf * bricks));
+            const size_t brick_smem = 2 * kPatchBytes + sizeof(BrickShared);
+            const FastDiv d_bricks = fast_divisor(static_cast<unsigned>(bricks));
+            const FastDiv d_nbz = fast_divisor(static_cast<unsigned>(vz / kBrick));
+            const FastDiv d_nby = fast_divisor(static_cast<unsigned>(vy / kBrick));
+#define MVX_LAUNCH_BRICK(AGG)                                                                                       \
+    hipLaunchKernelGGL((unproject_brick32<AGG>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, vc, h, w, \
+                       vx, vy, vz, d_bricks, d_nbz, d_nby, sx, sy, vo)
+            switch (aggregation) {
+                case MVX_AGG_SUM: MVX_LAUNCH_BRICK(MVX_AGG_SUM); break;
+                case MVX_AGG_CONF: MVX_LAUNCH_BRICK(MVX_AGG_CONF); break;
+                case MVX_AGG_MAX: MVX_LAUNCH_BRICK(MVX_AGG_MAX); break;
+                default: MVX_LAUNCH_BRICK(MVX_AGG_SOFTMAX); break;
+            }
+#undef MVX_LAUNCH_BRICK
+        } else if (tiled) {
             const int64_t tiles = n_voxels / kTile;
             MVX_REQUIRE(nf * tiles <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
             const dim3 grid(static_cast<unsigned>(nf * tiles));

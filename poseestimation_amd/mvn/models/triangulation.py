@@ -357,6 +357,30 @@ class VolumetricTriangulationNet(nn.Module):
         K[:, :, 1, 2] *= ry
         return np.matmul(K, Rt)
 
+    def _process_features_channel_last(self, features):
+        """`self.process_features(features)` (mvn/models/triangulation.py:388-390: a 1 x 1 convolution 256 -> 32)
+        with the result laid out channel-last in memory, which is the layout the unprojection samples in place:
+        the convolution is evaluated as one batched matrix product (N, HW, 256) x (256, 32) whose output rows are
+        the pixels, so the channel-last maps come out of the product itself and no layout copy follows.  Same
+        values up to the summation order of the product; the returned tensor has the usual logical shape
+        (N, 32, h, w).  Anything else (another module in `process_features`, a module in training mode with autograd
+        recording) goes through the module as it is."""
+        conv = self.process_features[0] if len(self.process_features) == 1 else None
+        plain = (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+                 and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1)
+                 and features.is_cuda and features.dtype == torch.float32)
+        if not plain or (self.training and torch.is_grad_enabled()):
+            return self.process_features(features)
+        n, c, h, w = features.shape
+        features = features.detach()
+        weight = conv.weight.detach().view(conv.out_channels, c)
+        pixels = features.reshape(n, c, h * w).transpose(1, 2)                 # (N, HW, C_in): a view, not a copy
+        if conv.bias is not None:
+            out = torch.baddbmm(conv.bias.detach().view(1, 1, -1), pixels, weight.t().unsqueeze(0).expand(n, -1, -1))
+        else:
+            out = torch.matmul(pixels, weight.t())
+        return out.view(n, h, w, conv.out_channels).permute(0, 3, 1, 2)        # logical (N, C_out, h, w)
+
     def forward(self, images, proj_matricies, batch):
         device = images.device
         batch_size, n_views = images.shape[:2]
@@ -381,7 +405,7 @@ class VolumetricTriangulationNet(nn.Module):
         cuboids = [volumetric.Cuboid3D(positions[i], sides) for i in range(batch_size)]
 
         features = features.view(-1, *features.shape[2:])
-        features = self.process_features(features)
+        features = self._process_features_channel_last(features)
         features = features.view(batch_size, n_views, *features.shape[1:])
 
         with _inference_guard(self):

@@ -297,6 +297,44 @@ def test_unproject_kernel_paths_agree(side, views):
     assert torch.allclose(full[:, :, :31, :, :15], generic, rtol=0, atol=2e-6)
 
 
+@pytest.fixture
+def no_bricks():
+    """Takes the brick kernel out of mvx_unproject's choice for the duration of a test."""
+    lib = _cabi.load()
+
+    def switch(off):
+        lib.mvx_set_kernel_selection(_cabi.SELECT_NO_UNPROJECT_BRICKS if off else 0)
+    yield switch
+    lib.mvx_set_kernel_selection(0)
+
+
+@pytest.mark.parametrize("side,shape", [(2500.0, (64, 64, 64)), (2500.0, (16, 8, 24)), (9000.0, (32, 32, 32)),
+                                        (30000.0, (32, 32, 32)), (600.0, (32, 32, 32))])
+def test_unproject_brick_kernel_equals_tile_kernel(side, shape, no_bricks):
+    """The brick kernel (patches of the maps staged in LDS) and the tile kernel (taps from global memory) share
+    their arithmetic: bit-identical volumes for all aggregations.  2.5 m: the reference's cuboid; 9 m and 30 m:
+    bricks whose patches exceed 16 x 16 pixels or that straddle / miss the maps (direct path inside the brick
+    kernel); 0.6 m: many voxels per pixel."""
+    case = synth.volumetric_case(23, 2, 4, volume_size=64, cuboid_side=side, with_volumes=False)
+    feats, proj, vconf = (to_dev(case[k]) for k in ("features", "proj", "vol_confidences"))
+    coord = to_dev(np.ascontiguousarray(case["coord_volumes"][:, :shape[0], :shape[1], :shape[2]]))
+    for method in ("sum", "conf", "max", "softmax"):
+        no_bricks(False)
+        brick = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+        no_bricks(True)
+        tile = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+        assert torch.equal(brick, tile), method
+    # coordinates that are no grid at all (shuffled voxels): the corner test cannot vouch for the patches, the
+    # per-lane check sends the bricks down the direct path
+    no_bricks(False)
+    flat = coord.view(2, -1, 3)
+    perm = torch.randperm(flat.shape[1], generator=torch.Generator().manual_seed(1)).to(dev())
+    shuffled = flat[:, perm].contiguous().view(coord.shape)
+    got = op.unproject_heatmaps(feats, proj, shuffled, "softmax", vconf)
+    want = brick.view(2, 32, -1)[:, :, perm].view(brick.shape)
+    assert torch.equal(got, want)
+
+
 def test_unproject_channels_last_input_is_sampled_in_place():
     """Feature maps in torch.channels_last memory give the same volumes, bit for bit, without the layout copy:
     the tile kernel (C = 32), the generic kernel (C = 8) and a C that is not a multiple of 4 (copied as usual)."""

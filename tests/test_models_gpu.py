@@ -128,6 +128,8 @@ def test_volumetric_forward_matches_reference_forward(kind, method, training):
     else:
         assert np.array_equal(cvol.cpu().numpy(), g[tag + "_coord_volumes"])
     np.testing.assert_allclose(f.cpu().numpy(), g[tag + "_features"], rtol=1e-4, atol=1e-5)
+    # the 1 x 1 convolution leaves its maps channel-last in memory, so the unprojection sampled them in place
+    assert tuple(f.shape) == (B, V, 32) + tuple(f.shape[3:]) and op._is_channels_last(f)
     if vc is not None:
         np.testing.assert_allclose(vc.cpu().numpy(), g[tag + "_vol_conf"], rtol=1e-6)
     # volumes come out of a softmax over 512 voxels; keypoints are millimetres
