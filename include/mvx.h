@@ -140,6 +140,19 @@ int mvx_unproject_channels_last(const float* features, const float* proj, const 
                                 int aggregation, float* volumes, void* stream);
 
 /*
+ * mvx_unproject / mvx_unproject_channels_last with the voxel positions given by the parameters of a regular grid
+ * instead of a coordinate volume (see mvx_soft_argmax_3d_grid): replaces mvn/utils/op.py:99-166 for the grid that
+ * mvn/models/triangulation.py:341-385 builds, without reading its 12 bytes per voxel; bit-identical to mvx_unproject
+ * fed the volume mvx_build_coord_volumes writes for the same parameters.  channels_last != 0: features are
+ * [n_frames][n_views][h][w][n_channels] and no workspace is needed; otherwise as mvx_unproject.
+ */
+int mvx_unproject_grid(const float* features, int channels_last, const float* proj, const float* position,
+                       const float* center, const float* rotation, float step0, float step1, float step2,
+                       int swap_yz_flip, const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
+                       int w, int vx, int vy, int vz, int aggregation, float* volumes, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/*
  * Soft-argmax over voxel grids.
  * coords_volume != NULL replaces mvn/utils/op.py:84-96 (integrate_tensor_3d_with_coordinates):
  *   softmax != 0: p = softmax over the grid; out = sum p * coord;  softmax == 0: p = max(x,0), out = sum p * coord.
@@ -157,6 +170,18 @@ size_t mvx_soft_argmax_3d_workspace_bytes(int64_t n_frames, int n_volumes, int s
 int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes, int sx,
                        int sy, int sz, float multiplier, int softmax, float* out, float* volumes_out,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * mvx_soft_argmax_3d with the voxel positions given by the parameters of a regular grid instead of a coordinate
+ * volume: the grid VolumetricTriangulationNet.forward builds (mvn/models/triangulation.py:341-385) is evaluated inside
+ * the kernel, in the float32 operation order of mvx_build_coord_volumes, so the result is bit-identical to
+ * mvx_soft_argmax_3d fed the volume that mvx_build_coord_volumes writes for the same parameters, and the 12 bytes per
+ * voxel of that volume are never read.  Grid arguments as in mvx_build_coord_volumes (s0, s1, s2 = sx, sy, sz).
+ */
+int mvx_soft_argmax_3d_grid(const float* volumes, const float* position, const float* center, const float* rotation,
+                            float step0, float step1, float step2, int swap_yz_flip, int64_t n_frames, int n_volumes,
+                            int sx, int sy, int sz, float multiplier, int softmax, float* out, float* volumes_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * mvx_soft_argmax_3d for callers that cannot allocate device memory (code under HIP graph capture, tight

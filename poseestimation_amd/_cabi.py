@@ -35,9 +35,13 @@ SIGNATURES = {
                              _vp]),
     "mvx_unproject_channels_last": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
                                            _vp]),
+    "mvx_unproject_grid": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _vp, _i64, _int, _int, _int, _int,
+                                  _int, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "mvx_build_coord_volumes": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _f32, _f32, _int, _vp, _vp]),
     "mvx_soft_argmax_3d_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "mvx_soft_argmax_3d": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _sz, _vp]),
+    "mvx_soft_argmax_3d_grid": (_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _i64, _int, _int, _int, _int, _f32, _int,
+                                       _vp, _vp, _vp, _sz, _vp]),
     "mvx_soft_argmax_3d_static": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp]),
     "mvx_heatmap_argmax": (_int, [_vp, _i64, _int, _int, _f32, _f32, _vp, _vp]),
     "mvx_triangulate_ransac": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, ctypes.c_double, _int, _vp, _vp, _vp]),

@@ -9,13 +9,19 @@
 // re-reads the volumes and writes exp(t - M) / S.  (Feeding the passes a few frames at a time so that the second
 // read would hit the Infinity Cache was measured slower than full-batch launches: small launches leave CUs idle.)
 //
+// Coordinates come from a coordinate volume, from the voxel index (integrate_tensor_3d), or from the parameters of
+// a regular grid (grid_coords.h), in which case no coordinate bytes are read at all.
+//
 // Algorithmic bytes per frame: J*N*4 (volumes) + N*12 (coordinates) [+ J*N*4 written] + J*12 out; with the
-// write-back the volumes cross HBM a second time on the read side.
+// write-back the volumes cross HBM a second time on the read side.  (A one-read variant -- teams of 4 to 16
+// workgroups holding a volume in registers as exp(t - own max), exchanging 40-byte records through memory and
+// rescaling on the way out -- was built, verified and measured slower on MI355X, 0.74 to 0.93 ms against 0.61 ms for
+// 64 frames: a compute unit alternates between its read phase and its write phase instead of overlapping them.)
 #include <stdlib.h>
 
 #include <mutex>
 
-#include "mvx_common.h"
+#include "grid_coords.h"
 
 namespace mvx {
 
@@ -45,31 +51,45 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ p, int64_t i, 
     }
 }
 
-// Coordinates of the four voxels i..i+3 (zeros past the end).
+// Where the voxel positions come from.
+struct CoordSource {
+    const float* volume;  // coordinate volume [n_frames][N][3], or NULL
+    GridSpec grid;        // used when has_grid
+    int has_grid;
+};
+
+// Coordinates of the four voxels i..i+3 of frame b (zeros past the end).
 template <bool VEC>
-__device__ __forceinline__ void load_coords4(const float* __restrict__ coord, int64_t i, int64_t n, Grid3 g,
+__device__ __forceinline__ void load_coords4(const CoordSource& src, int64_t b, int64_t i, int64_t n, Grid3 g,
                                              float (&cx)[4], float (&cy)[4], float (&cz)[4]) {
-    if (coord == nullptr) {  // index space: voxel (x, y, z) of the flat index
+    if (src.volume == nullptr) {  // voxel (x, y, z) of the flat index: index space, or the grid evaluated there
+        FrameGrid fg;
+        if (src.has_grid) fg.load(src.grid, b, g.sy);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t v = i + k;
-            const int z = static_cast<int>(v % g.sz);
-            const int y = static_cast<int>((v / g.sz) % g.sy);
-            const int x = static_cast<int>(v / (static_cast<int64_t>(g.sz) * g.sy));
             const bool ok = v < n;
-            cx[k] = ok ? static_cast<float>(x) : 0.0f;
-            cy[k] = ok ? static_cast<float>(y) : 0.0f;
-            cz[k] = ok ? static_cast<float>(z) : 0.0f;
+            // 32-bit arithmetic (the host limits the grid to 2^31 voxels); past the end any in-range index will do
+            const unsigned vu = ok ? static_cast<unsigned>(v) : 0u;
+            const unsigned row = vu / static_cast<unsigned>(g.sz);
+            const int z = static_cast<int>(vu - row * static_cast<unsigned>(g.sz));
+            const int x = static_cast<int>(row / static_cast<unsigned>(g.sy)), y = static_cast<int>(row) - x * g.sy;
+            float px = static_cast<float>(x), py = static_cast<float>(y), pz = static_cast<float>(z);
+            if (src.has_grid) fg.at(x, y, z, px, py, pz);
+            cx[k] = ok ? px : 0.0f;
+            cy[k] = ok ? py : 0.0f;
+            cz[k] = ok ? pz : 0.0f;
         }
         return;
     }
+    const float* coord = src.volume + b * n * 3;
     float f[12];
     if (VEC) {
         if (i < n) {
             const float4* p = reinterpret_cast<const float4*>(coord + i * 3);
-            const float4 a = p[0], b = p[1], c = p[2];
+            const float4 a = p[0], b4 = p[1], c = p[2];
             f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
-            f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+            f[4] = b4.x; f[5] = b4.y; f[6] = b4.z; f[7] = b4.w;
             f[8] = c.x; f[9] = c.y; f[10] = c.z; f[11] = c.w;
         } else {
 #pragma unroll
@@ -89,8 +109,8 @@ __device__ __forceinline__ void load_coords4(const float* __restrict__ coord, in
 
 // Pass 1.  grid.x = n_frames * blocks_per_frame; each wave handles segment (block_in_frame*4 + wave).
 template <int NV, bool VEC>
-__global__ __launch_bounds__(kThreads) void soft_argmax_3d_partial(const float* __restrict__ vol,
-                                                                    const float* __restrict__ coord, int J,
+__global__ __launch_bounds__(kThreads) void soft_argmax_3d_partial(const float* __restrict__ vol, CoordSource coord,
+                                                                    int J,
                                                                     int64_t n_vox, Grid3 g, int n_seg,
                                                                     int blocks_per_frame, float mult, int softmax,
                                                                     double* __restrict__ partial) {
@@ -102,9 +122,8 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_partial(const float* 
     const int64_t base = static_cast<int64_t>(seg) * kSeg;
 
     float cx[NV][4], cy[NV][4], cz[NV][4];
-    const float* cb = coord != nullptr ? coord + b * n_vox * 3 : nullptr;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) load_coords4<VEC>(cb, base + (k * 64 + lane) * 4, n_vox, g, cx[k], cy[k], cz[k]);
+    for (int k = 0; k < NV; ++k) load_coords4<VEC>(coord, b, base + (k * 64 + lane) * 4, n_vox, g, cx[k], cy[k], cz[k]);
 
     const float fill = softmax ? -INFINITY : 0.0f;
     const float* vb = vol + b * J * n_vox;
@@ -287,9 +306,11 @@ extern "C" size_t mvx_soft_argmax_3d_workspace_bytes(int64_t n_frames, int n_vol
 
 namespace mvx {
 namespace {
-int soft_argmax_3d_any(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes, int sx, int sy,
-                       int sz, float multiplier, int softmax, float* out, float* volumes_out, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+// `index_space`: the expectation of the voxel index (integrate_tensor_3d) rather than of a position.
+int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool index_space, int64_t n_frames, int n_volumes,
+                       int sx, int sy, int sz, float multiplier, int softmax, float* out, float* volumes_out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    const float* coords_volume = coord.volume;
     MVX_REQUIRE(n_frames >= 0 && n_volumes >= 0 && sx > 0 && sy > 0 && sz > 0, MVX_ERR_INVALID_ARGUMENT,
                 "mvx_soft_argmax_3d: bad shape n_frames=%lld n_volumes=%d grid=%dx%dx%d", (long long)n_frames,
                 n_volumes, sx, sy, sz);
@@ -308,10 +329,10 @@ int soft_argmax_3d_any(const float* volumes, const float* coords_volume, int64_t
     const int64_t seg_len = 64 * nv * 4;
     const int64_t n_seg64 = (n_vox + seg_len - 1) / seg_len;
     const int64_t bpf64 = (n_seg64 + 3) / 4;
-    MVX_REQUIRE(n_seg64 <= (1 << 24), MVX_ERR_UNSUPPORTED, "mvx_soft_argmax_3d: grid of %lld voxels is too large",
-                (long long)n_vox);
+    MVX_REQUIRE(n_seg64 <= (1 << 24) && n_vox < (1LL << 31), MVX_ERR_UNSUPPORTED,
+                "mvx_soft_argmax_3d: grid of %lld voxels is too large", (long long)n_vox);
     const int n_seg = static_cast<int>(n_seg64), bpf = static_cast<int>(bpf64);
-    const int mode = softmax ? 0 : (coords_volume != nullptr ? 1 : 2);
+    const int mode = softmax ? 0 : (index_space ? 2 : 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partial = static_cast<double*>(workspace);
 
@@ -324,7 +345,7 @@ int soft_argmax_3d_any(const float* volumes, const float* coords_volume, int64_t
 
     const dim3 grid1(static_cast<unsigned>(n_frames * bpf)), block(kThreads);
 #define MVX_LAUNCH_PARTIAL(NV, VEC)                                                                              \
-    hipLaunchKernelGGL((soft_argmax_3d_partial<NV, VEC>), grid1, block, 0, st, volumes, coords_volume, n_volumes, \
+    hipLaunchKernelGGL((soft_argmax_3d_partial<NV, VEC>), grid1, block, 0, st, volumes, coord, n_volumes, \
                        n_vox, g, n_seg, bpf, multiplier, softmax, partial)
     if (nv == 4 && vec) MVX_LAUNCH_PARTIAL(4, true);
     else if (nv == 4) MVX_LAUNCH_PARTIAL(4, false);
@@ -354,7 +375,25 @@ int soft_argmax_3d_any(const float* volumes, const float* coords_volume, int64_t
 extern "C" int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes,
                                   int sx, int sy, int sz, float multiplier, int softmax, float* out,
                                   float* volumes_out, void* workspace, size_t workspace_bytes, void* stream) {
-    return mvx::soft_argmax_3d_any(volumes, coords_volume, n_frames, n_volumes, sx, sy, sz, multiplier, softmax, out,
+    mvx::CoordSource src{};
+    src.volume = coords_volume;
+    return mvx::soft_argmax_3d_any(volumes, src, coords_volume == nullptr, n_frames, n_volumes, sx, sy, sz, multiplier,
+                                   softmax, out, volumes_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvx_soft_argmax_3d_grid(const float* volumes, const float* position, const float* center,
+                                       const float* rotation, float step0, float step1, float step2, int swap_yz_flip,
+                                       int64_t n_frames, int n_volumes, int sx, int sy, int sz, float multiplier,
+                                       int softmax, float* out, float* volumes_out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (n_frames > 0 && n_volumes > 0) {
+        const int rc = mvx::check_grid_spec("mvx_soft_argmax_3d_grid", position, center, rotation, swap_yz_flip, sy, sz);
+        if (rc != MVX_OK) return rc;
+    }
+    mvx::CoordSource src{};
+    src.grid = mvx::GridSpec{position, center, rotation, step0, step1, step2, swap_yz_flip};
+    src.has_grid = 1;
+    return mvx::soft_argmax_3d_any(volumes, src, false, n_frames, n_volumes, sx, sy, sz, multiplier, softmax, out,
                                    volumes_out, workspace, workspace_bytes, stream);
 }
 
@@ -409,6 +448,8 @@ extern "C" int mvx_soft_argmax_3d_static(const float* volumes, const float* coor
     if (rc != MVX_OK) return rc;
     // every record and pair that the later passes read is rewritten by the earlier pass of the same call, so the
     // contents a previous call left behind need no clearing
-    return soft_argmax_3d_any(volumes, coords_volume, n_frames, n_volumes, sx, sy, sz, multiplier, softmax, out,
-                              volumes_out, ws, MVX_SOFT_ARGMAX_3D_STATIC_BYTES, stream);
+    CoordSource src{};
+    src.volume = coords_volume;
+    return soft_argmax_3d_any(volumes, src, coords_volume == nullptr, n_frames, n_volumes, sx, sy, sz, multiplier,
+                              softmax, out, volumes_out, ws, MVX_SOFT_ARGMAX_3D_STATIC_BYTES, stream);
 }

@@ -30,7 +30,7 @@
 #include <limits.h>
 #include <stdlib.h>
 
-#include "mvx_common.h"
+#include "grid_coords.h"
 
 namespace mvx {
 
@@ -46,6 +46,38 @@ struct Tap {
 
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
+
+// Where the world position of a voxel comes from: a coordinate volume [frames of this launch][N][3], or the
+// parameters of a regular grid evaluated on the spot (grid_coords.h), frame index relative to `first_frame`.
+struct VoxelSource {
+    const float* volume;
+    GridSpec grid;
+    int has_grid;
+    int64_t first_frame;  // frame of the batch that frame 0 of this launch is
+    int vy, vz;           // grid dimensions 1 and 2
+};
+// Position of voxel n (flat index) of frame b of the launch.
+__device__ __forceinline__ void voxel_position(const VoxelSource& src, int64_t b, int64_t n_vox, int64_t n, double& X,
+                                               double& Y, double& Z) {
+    if (src.has_grid) {
+        const unsigned nu = static_cast<unsigned>(n);
+        const unsigned row = nu / static_cast<unsigned>(src.vz);
+        const int i2 = static_cast<int>(nu - row * static_cast<unsigned>(src.vz));
+        const int i0 = static_cast<int>(row / static_cast<unsigned>(src.vy)), i1 = static_cast<int>(row) - i0 * src.vy;
+        FrameGrid fg;
+        fg.load(src.grid, src.first_frame + b, src.vy);
+        float x, y, z;
+        fg.at(i0, i1, i2, x, y, z);
+        X = x;
+        Y = y;
+        Z = z;
+    } else {
+        const float* cp = src.volume + (b * n_vox + n) * 3;
+        X = cp[0];
+        Y = cp[1];
+        Z = cp[2];
+    }
+}
 
 // Projects one voxel and returns its bilinear taps with zero padding.
 // The reference maps the projected pixel (x, y) = (u/z, v/z) through gx = 2(x/H - 0.5), gy = 2(y/W - 0.5)
@@ -292,7 +324,7 @@ __global__ __launch_bounds__(kThreads) void to_channel_last(const float* __restr
 template <int AGG>
 __global__ __launch_bounds__(kThreads) void unproject_generic(const float* __restrict__ feat_cl,
                                                               const float* __restrict__ proj,
-                                                              const float* __restrict__ coord,
+                                                              VoxelSource coord,
                                                               const float* __restrict__ vconf, int64_t n_items,
                                                               int V, int C, int Cp, int H, int W, int64_t n_vox,
                                                               double sx, double sy, float* __restrict__ vol) {
@@ -302,8 +334,8 @@ __global__ __launch_bounds__(kThreads) void unproject_generic(const float* __res
     const int q = static_cast<int>(idx % Cq);
     const int64_t bn = idx / Cq;
     const int64_t b = bn / n_vox, n = bn - b * n_vox;
-    const float* cp = coord + (b * n_vox + n) * 3;
-    const double X = cp[0], Y = cp[1], Z = cp[2];
+    double X, Y, Z;
+    voxel_position(coord, b, n_vox, n, X, Y, Z);
     Aggregator<AGG> agg;
     agg.init();
     for (int v = 0; v < V; ++v) {
@@ -335,7 +367,7 @@ constexpr int kTileMaxViews = 16;
 template <int AGG, bool FOUR>
 __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __restrict__ feat_cl,
                                                              const float* __restrict__ proj,
-                                                             const float* __restrict__ coord,
+                                                             VoxelSource coord,
                                                              const float* __restrict__ vconf, int V, int H, int W,
                                                              int64_t n_vox, int tiles_per_frame, double sx, double sy,
                                                              float* __restrict__ vol) {
@@ -357,8 +389,8 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
     __syncthreads();
     {
         const int t = tid & (kTile - 1);
-        const float* cp = coord + (b * n_vox + n0 + t) * 3;
-        const double X = cp[0], Y = cp[1], Z = cp[2];
+        double X, Y, Z;
+        voxel_position(coord, b, n_vox, n0 + t, X, Y, Z);
         for (int v = tid / kTile; v < V; v += kThreads / kTile) {
             const Tap tap = project_tap(cam + v * 12, X, Y, Z, H, W, AGG == MVX_AGG_SOFTMAX ? kLog2e : 1.0f);
             wts[v * kTile + t] = make_float4(tap.w00, tap.w01, tap.w10, tap.w11);
@@ -550,10 +582,10 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], int lane) {
     }
 }
 
-template <int AGG>
+template <int AGG, bool GRID>
 __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const float* __restrict__ feat_cl,
                                                                        const float* __restrict__ proj,
-                                                                       const float* __restrict__ coord,
+                                                                       VoxelSource coord,
                                                                        const float* __restrict__ vconf, int H, int W,
                                                                        int vx, int vy, int vz, FastDiv bricks_per_frame,
                                                                        FastDiv nbz, FastDiv nby, double sx, double sy,
@@ -591,8 +623,21 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
 
     // 1./2. projection, patch rectangles and per-lane check, a pair of views at a time: the patches of views 0 and 1
     // are on their way into LDS while views 2 and 3 are projected.
-    const float* cp = coord + (b * n_vox + n) * 3;
-    const double X = cp[0], Y = cp[1], Z = cp[2];
+    double X, Y, Z;
+    if (GRID) {
+        FrameGrid fg;
+        fg.load(coord.grid, coord.first_frame + b, vy);
+        float x, y, z;
+        fg.at(bx * kBrick + lx, by * kBrick + ly, bz * kBrick + lz, x, y, z);
+        X = x;
+        Y = y;
+        Z = z;
+    } else {
+        const float* cp = coord.volume + (b * n_vox + n) * 3;
+        X = cp[0];
+        Y = cp[1];
+        Z = cp[2];
+    }
     float4 wt[4];
     int txb[4], tyb[4];
     int ox[4], oy[4], rows[4];
@@ -845,7 +890,7 @@ namespace mvx {
 namespace {
 // channels_last: features are [n_frames][n_views][h][w][n_channels] already and no workspace is used.
 int unproject_any_layout(const char* name, bool channels_last, const float* features, const float* proj,
-                         const float* coords, const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
+                         const float* coords, const GridSpec* grid_spec, const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
                          int w, int vx, int vy, int vz, int aggregation, float* volumes, void* workspace,
                          size_t workspace_bytes, void* stream);
 }  // namespace
@@ -854,7 +899,7 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
 extern "C" int mvx_unproject(const float* features, const float* proj, const float* coords, const float* vol_conf,
                              int64_t n_frames, int n_views, int n_channels, int h, int w, int vx, int vy, int vz,
                              int aggregation, float* volumes, void* workspace, size_t workspace_bytes, void* stream) {
-    return mvx::unproject_any_layout("mvx_unproject", false, features, proj, coords, vol_conf, n_frames, n_views,
+    return mvx::unproject_any_layout("mvx_unproject", false, features, proj, coords, nullptr, vol_conf, n_frames, n_views,
                                      n_channels, h, w, vx, vy, vz, aggregation, volumes, workspace, workspace_bytes,
                                      stream);
 }
@@ -863,14 +908,31 @@ extern "C" int mvx_unproject_channels_last(const float* features, const float* p
                                            const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
                                            int w, int vx, int vy, int vz, int aggregation, float* volumes,
                                            void* stream) {
-    return mvx::unproject_any_layout("mvx_unproject_channels_last", true, features, proj, coords, vol_conf, n_frames,
+    return mvx::unproject_any_layout("mvx_unproject_channels_last", true, features, proj, coords, nullptr, vol_conf, n_frames,
                                      n_views, n_channels, h, w, vx, vy, vz, aggregation, volumes, nullptr, 0, stream);
+}
+
+extern "C" int mvx_unproject_grid(const float* features, int channels_last, const float* proj, const float* position,
+                                  const float* center, const float* rotation, float step0, float step1, float step2,
+                                  int swap_yz_flip, const float* vol_conf, int64_t n_frames, int n_views,
+                                  int n_channels, int h, int w, int vx, int vy, int vz, int aggregation, float* volumes,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_frames > 0) {
+        const int rc = mvx::check_grid_spec("mvx_unproject_grid", position, center, rotation, swap_yz_flip, vy, vz);
+        if (rc != MVX_OK) return rc;
+        MVX_REQUIRE(static_cast<int64_t>(vx) * vy * vz < (1LL << 31), MVX_ERR_UNSUPPORTED,
+                    "mvx_unproject_grid: grid of %dx%dx%d voxels is too large", vx, vy, vz);
+    }
+    const mvx::GridSpec spec{position, center, rotation, step0, step1, step2, swap_yz_flip};
+    return mvx::unproject_any_layout("mvx_unproject_grid", channels_last != 0, features, proj, nullptr, &spec, vol_conf,
+                                     n_frames, n_views, n_channels, h, w, vx, vy, vz, aggregation, volumes, workspace,
+                                     workspace_bytes, stream);
 }
 
 namespace mvx {
 namespace {
 int unproject_any_layout(const char* name, bool channels_last, const float* features, const float* proj,
-                         const float* coords, const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
+                         const float* coords, const GridSpec* grid_spec, const float* vol_conf, int64_t n_frames, int n_views, int n_channels, int h,
                          int w, int vx, int vy, int vz, int aggregation, float* volumes, void* workspace,
                          size_t workspace_bytes, void* stream) {
     MVX_REQUIRE(n_frames >= 0 && n_views > 0 && n_channels > 0 && h >= 2 && w >= 2 && vx >= 0 && vy >= 0 && vz >= 0,
@@ -880,7 +942,7 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
     MVX_REQUIRE(aggregation >= MVX_AGG_SUM && aggregation <= MVX_AGG_SOFTMAX, MVX_ERR_INVALID_ARGUMENT,
                 "%s: unknown aggregation %d", name, aggregation);
     if (n_frames == 0 || n_voxels == 0) return MVX_OK;
-    MVX_REQUIRE(features != nullptr && proj != nullptr && coords != nullptr && volumes != nullptr &&
+    MVX_REQUIRE(features != nullptr && proj != nullptr && (coords != nullptr || grid_spec != nullptr) && volumes != nullptr &&
                     (channels_last || workspace != nullptr),
                 MVX_ERR_INVALID_ARGUMENT, "%s: null pointer argument", name);
     MVX_REQUIRE(aggregation != MVX_AGG_CONF || vol_conf != nullptr, MVX_ERR_INVALID_ARGUMENT,
@@ -927,7 +989,15 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
             feat_cl = static_cast<const float*>(workspace);
         }
         const float* pj = proj + f0 * V * 12;
-        const float* cd = coords + f0 * n_voxels * 3;
+        VoxelSource cd{};
+        cd.volume = coords != nullptr ? coords + f0 * n_voxels * 3 : nullptr;
+        if (grid_spec != nullptr) {
+            cd.grid = *grid_spec;
+            cd.has_grid = 1;
+        }
+        cd.first_frame = f0;
+        cd.vy = vy;
+        cd.vz = vz;
         const float* vc = vol_conf != nullptr ? vol_conf + f0 * V * C : nullptr;
         float* vo = volumes + f0 * C * n_voxels;
         if (bricked) {
@@ -938,9 +1008,13 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
             const FastDiv d_bricks = fast_divisor(static_cast<unsigned>(bricks));
             const FastDiv d_nbz = fast_divisor(static_cast<unsigned>(vz / kBrick));
             const FastDiv d_nby = fast_divisor(static_cast<unsigned>(vy / kBrick));
-#define MVX_LAUNCH_BRICK(AGG)                                                                                       \
-    hipLaunchKernelGGL((unproject_brick32<AGG>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, vc, h, w, \
-                       vx, vy, vz, d_bricks, d_nbz, d_nby, sx, sy, vo)
+#define MVX_LAUNCH_BRICK(AGG)                                                                                      \
+    if (cd.has_grid)                                                                                              \
+        hipLaunchKernelGGL((unproject_brick32<AGG, true>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, \
+                           vc, h, w, vx, vy, vz, d_bricks, d_nbz, d_nby, sx, sy, vo);                             \
+    else                                                                                                          \
+        hipLaunchKernelGGL((unproject_brick32<AGG, false>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, \
+                           vc, h, w, vx, vy, vz, d_bricks, d_nbz, d_nby, sx, sy, vo)
             switch (aggregation) {
                 case MVX_AGG_SUM: MVX_LAUNCH_BRICK(MVX_AGG_SUM); break;
                 case MVX_AGG_CONF: MVX_LAUNCH_BRICK(MVX_AGG_CONF); break;

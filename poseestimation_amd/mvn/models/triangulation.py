@@ -333,6 +333,8 @@ class VolumetricTriangulationNet(nn.Module):
                 _cabi.ptr(pos), _cabi.ptr(center), _cabi.ptr(rot), B, S, S, S, step, step, step,
                 int(bool(self.transfer_cmu_to_human36m)), _cabi.ptr(coord), _cabi.stream(device))
         _cabi.check(st, "mvx_build_coord_volumes")
+        # the ops downstream evaluate the grid themselves instead of reading this tensor back (same values)
+        op.attach_grid(coord, op.VoxelGrid(pos, center, rot, (step, step, step), self.transfer_cmu_to_human36m, (S, S, S)))
         return coord, position
 
     @staticmethod

@@ -9,6 +9,37 @@ import torch
 from poseestimation_amd import _cabi
 
 
+class VoxelGrid:
+    """Parameters of a regular voxel grid on a HIP device: what mvx_build_coord_volumes turns into a coordinate
+    volume.  position, center (n_frames, 3) and rotation (n_frames, 9) are float32 tensors; step = voxel pitch per
+    axis; swap_yz_flip = the CMU-to-Human3.6M axis transfer."""
+
+    def __init__(self, position, center, rotation, step, swap_yz_flip, shape):
+        self.position, self.center, self.rotation = position, center, rotation
+        self.step = tuple(float(x) for x in step)
+        self.swap_yz_flip = int(bool(swap_yz_flip))
+        self.shape = tuple(int(x) for x in shape)
+
+
+def attach_grid(coord_volumes, grid):
+    """Marks `coord_volumes` (n_frames, x, y, z, 3) as the materialised form of `grid`.  The functions of this module
+    then evaluate the grid inside their kernels instead of reading the tensor (same float32 operation order: the
+    results are bit-identical), as long as the tensor has not been modified in place since and is passed on as the
+    same object (a slice or copy is an ordinary tensor again)."""
+    coord_volumes._mvx_grid = (grid, coord_volumes._version)
+    return coord_volumes
+
+
+def _grid_of(coord_volumes, n_frames, vshape):
+    tag = getattr(coord_volumes, "_mvx_grid", None)
+    if tag is None or tag[1] != coord_volumes._version:
+        return None
+    grid = tag[0]
+    if grid.shape != tuple(vshape) or grid.position.shape[0] != n_frames or grid.position.device != coord_volumes.device:
+        return None
+    return grid
+
+
 def _soft_argmax_2d(heatmaps, softmax, multiplier, return_heatmaps):
     _cabi.forward_only("integrate_tensor_2d", heatmaps)
     hm = _cabi.device_f32(heatmaps, "heatmaps")
@@ -55,10 +86,18 @@ def _soft_argmax_3d(volumes, coord_volumes, softmax, multiplier, return_volumes)
     lib = _cabi.load()
     ws_bytes = lib.mvx_soft_argmax_3d_workspace_bytes(b, n, sx, sy, sz)
     ws = torch.empty((max(ws_bytes, 8) + 7) // 8, dtype=torch.float64, device=vol.device)
+    grid = _grid_of(coord_volumes, b, (sx, sy, sz)) if coord_volumes is not None else None
     with torch.cuda.device(vol.device):
-        st = lib.mvx_soft_argmax_3d(_cabi.ptr(vol), _cabi.ptr(cv), b, n, sx, sy, sz, float(multiplier),
-                                    int(bool(softmax)), _cabi.ptr(coords), _cabi.ptr(out), _cabi.ptr(ws),
-                                    ws.numel() * 8, _cabi.stream(vol.device))
+        if grid is not None:   # the grid is evaluated in the kernel: its 12 bytes per voxel are not read
+            st = lib.mvx_soft_argmax_3d_grid(_cabi.ptr(vol), _cabi.ptr(grid.position), _cabi.ptr(grid.center),
+                                             _cabi.ptr(grid.rotation), grid.step[0], grid.step[1], grid.step[2],
+                                             grid.swap_yz_flip, b, n, sx, sy, sz, float(multiplier), int(bool(softmax)),
+                                             _cabi.ptr(coords), _cabi.ptr(out), _cabi.ptr(ws), ws.numel() * 8,
+                                             _cabi.stream(vol.device))
+        else:
+            st = lib.mvx_soft_argmax_3d(_cabi.ptr(vol), _cabi.ptr(cv), b, n, sx, sy, sz, float(multiplier),
+                                        int(bool(softmax)), _cabi.ptr(coords), _cabi.ptr(out), _cabi.ptr(ws),
+                                        ws.numel() * 8, _cabi.stream(vol.device))
     _cabi.check(st, "mvx_soft_argmax_3d")
     return coords, out
 
@@ -131,20 +170,30 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
     _cabi.same_device(feats, "heatmaps", proj_matricies=proj, coord_volumes=cv, vol_confidences=vc)
     volumes = torch.empty((b, c) + vshape, dtype=torch.float32, device=feats.device)
     lib = _cabi.load()
-    if channels_last:   # the maps are sampled where they lie: no layout copy, no workspace
-        with torch.cuda.device(feats.device):
-            st = lib.mvx_unproject_channels_last(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c,
-                                                 h, w, vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(volumes),
-                                                 _cabi.stream(feats.device))
-        _cabi.check(st, "mvx_unproject_channels_last")
-        return volumes
-    ws_bytes = lib.mvx_unproject_workspace_bytes(b, v, c, h, w)
-    ws = torch.empty((max(ws_bytes, 16) + 15) // 16 * 4, dtype=torch.float32, device=feats.device)
+    grid = _grid_of(coord_volumes, b, vshape)
+    ws, ws_bytes = None, 0
+    if not channels_last:   # maps that are not channel-last in memory are first copied to that layout
+        ws_bytes = lib.mvx_unproject_workspace_bytes(b, v, c, h, w)
+        ws = torch.empty((max(ws_bytes, 16) + 15) // 16 * 4, dtype=torch.float32, device=feats.device)
+        ws_bytes = ws.numel() * 4
+    dev_stream = _cabi.stream(feats.device)
     with torch.cuda.device(feats.device):
-        st = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c, h, w,
-                               vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(volumes), _cabi.ptr(ws),
-                               ws.numel() * 4, _cabi.stream(feats.device))
-    _cabi.check(st, "mvx_unproject")
+        if grid is not None:   # the grid is evaluated in the kernel: its 12 bytes per voxel are not read
+            what = "mvx_unproject_grid"
+            st = lib.mvx_unproject_grid(_cabi.ptr(feats), int(channels_last), _cabi.ptr(proj), _cabi.ptr(grid.position),
+                                        _cabi.ptr(grid.center), _cabi.ptr(grid.rotation), grid.step[0], grid.step[1],
+                                        grid.step[2], grid.swap_yz_flip, _cabi.ptr(vc), b, v, c, h, w, vshape[0],
+                                        vshape[1], vshape[2], agg, _cabi.ptr(volumes), _cabi.ptr(ws), ws_bytes, dev_stream)
+        elif channels_last:    # the maps are sampled where they lie: no layout copy, no workspace
+            what = "mvx_unproject_channels_last"
+            st = lib.mvx_unproject_channels_last(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c,
+                                                 h, w, vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(volumes), dev_stream)
+        else:
+            what = "mvx_unproject"
+            st = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), b, v, c, h, w,
+                                   vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(volumes), _cabi.ptr(ws), ws_bytes,
+                                   dev_stream)
+    _cabi.check(st, what)
     return volumes
 
 
