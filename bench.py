@@ -240,9 +240,32 @@ def check_volumetric(feats, proj, coord, vols, unprojected, keypoints, frames_to
     return worst_u, worst_k
 
 
+def library_grid(base_points, dev, side=2500.0, size=64):
+    """The coordinate volumes of `base_points` (n, 3) as VolumetricTriangulationNet.build_coord_volumes makes them in
+    eval mode: written by mvx_build_coord_volumes and tagged with their grid parameters, so that the ops evaluate
+    the grid in their kernels instead of reading the tensor back."""
+    lib = _cabi.load()
+    n = base_points.shape[0]
+    center = base_points.to(device=dev, dtype=torch.float32).contiguous()
+    position = (center - side / 2).contiguous()
+    rot = torch.eye(3, dtype=torch.float32, device=dev).reshape(1, 9).repeat(n, 1).contiguous()
+    step = float(np.float32(side / (size - 1)))
+    coord = torch.empty((n, size, size, size, 3), dtype=torch.float32, device=dev)
+    rc = lib.mvx_build_coord_volumes(_cabi.ptr(position), _cabi.ptr(center), _cabi.ptr(rot), n, size, size, size, step, step,
+                                     step, 0, _cabi.ptr(coord), _cabi.stream(dev))
+    if rc != 0:
+        raise RuntimeError("mvx_build_coord_volumes failed: %s" % lib.mvx_last_error().decode())
+    return op.attach_grid(coord, op.VoxelGrid(position, center, rot, (step,) * 3, 0, (size,) * 3))
+
+
 def run_volumetric(args, dev, rank, world, frames=64):
+    """The two ops as VolumetricTriangulationNet.forward calls them: feature maps channel-last in memory (what its
+    1 x 1 convolution leaves) and coordinate volumes it built itself (grid parameters attached)."""
     case = synth.device_volumetric_case(1234 + 2 + rank, frames, 4, dev)
-    feats, proj, coord, vconf, vols = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
+    feats, proj, vconf, vols = (case[k] for k in ("features", "proj", "vol_confidences", "volumes"))
+    coord = library_grid(torch.from_numpy(case["base_points"]), dev)
+    b, v, c, h, w = feats.shape
+    fcl = feats.view(b * v, c, h, w).contiguous(memory_format=torch.channels_last).view(b, v, c, h, w)
     k3 = EventTimer()
     k4 = EventTimer()
     sg = StepGather((frames, 17, 3), dev, world)
@@ -251,11 +274,11 @@ def run_volumetric(args, dev, rank, world, frames=64):
         dst = sg.buffer()
         if timed:
             with k3:
-                u = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
+                u = op.unproject_heatmaps(fcl, proj, coord, "softmax", vconf)
             with k4:
                 kp, _ = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
         else:
-            u = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
+            u = op.unproject_heatmaps(fcl, proj, coord, "softmax", vconf)
             kp, _ = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
         dst.copy_(kp)
         sg.submit()
@@ -265,22 +288,28 @@ def run_volumetric(args, dev, rank, world, frames=64):
     u = step(False)
     own = sg.gathered()[rank * frames: (rank + 1) * frames] if world > 1 else sg.gathered()
     err_u, err_k = check_volumetric(feats, proj, coord, vols, u, own, sorted({0, frames // 7, frames // 2, frames - 1}))
+    # the plain-API form of the same call (maps [view][channel][h][w], an untagged coordinate tensor) gives the same bits
+    plain = coord.clone()
+    assert torch.equal(op.unproject_heatmaps(feats, proj, plain, "softmax", vconf), u)
     del u
     ms = timed_loop(step, args, dev, world, sg)
+    api = EventTimer()
+    for _ in range(5):
+        with api:
+            op.unproject_heatmaps(feats, proj, plain, "softmax", vconf)
+    torch.cuda.synchronize(dev)
     n_vox = 64 ** 3
     b3 = frames * (4 * 32 * 96 * 96 * 4 + n_vox * 12 + 32 * n_vox * 4)
     b4 = frames * (17 * n_vox * 4 * 2 + n_vox * 12)
-    roof = {"bound": "hbm", "kernel": "unproject (channel-last copy + unproject_tile32<softmax>)",
+    roof = {"bound": "hbm", "kernel": "unproject_brick32<softmax> (channel-last maps, grid parameters)",
             "achieved": b3 / (k3.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": b3, "avg_launch_ms": k3.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"], roof["traffic_source"] = measured_traffic("unproject", {"frames": frames, "views": 4, "method": "softmax"})
-    # the unprojection gathers 4 taps x 32 channels x 4 B per voxel and view through the vector L1; a CU returns
-    # 46 B/clk for loads of that shape when everything hits (tools/l1_bandwidth.hip: 28.2 TB/s over the chip)
-    tap_bytes = frames * n_vox * 4 * 512
     extra = {"soft_argmax_3d_ms": k4.mean_ms(), "soft_argmax_3d_GBps": b4 / (k4.mean_ms() * 1e-3) / 1e9,
              "soft_argmax_3d_frac_of_hbm_peak": b4 / (k4.mean_ms() * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             "unproject_tap_TBps": tap_bytes / (k3.mean_ms() * 1e-3) / 1e12, "measured_l1_gather_ceiling_TBps": 28.2,
+             "unproject_plain_api_ms": api.mean_ms(),
+             "unproject_plain_api_note": "maps [view][channel][h][w] (layout copy inside) and an untagged coordinate tensor",
              "max_abs_error_unproject_vs_float64_torch": err_u, "max_abs_error_keypoints_vs_float64_torch_mm": err_k}
     cfg = {"workload": "volumetric: unproject 4 views x 32ch 96x96 -> 64^3 (softmax) + 3-D soft-argmax of 17 volumes, %d frames/GPU"
                        % frames, "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world}
@@ -303,6 +332,8 @@ def run_sharded(args, dev, rank, world, total=65536, alg_block=4096, vol_block=6
     _, v, j, h, w = hm.shape
     vcase = synth.device_volumetric_case(1234 + 3 + rank, vol_block, 4, dev)
     feats, proj_hm, vols = vcase["features"], vcase["proj"], vcase["volumes"]
+    feats = feats.view(-1, 32, 96, 96).contiguous(memory_format=torch.channels_last).view(feats.shape)  # as the model leaves them
+    assert op._is_channels_last(feats)
     S, side = 64, 2500.0
     n_vox = S ** 3
     # outputs: per-frame keypoints of both legs side by side (one collective moves both)
@@ -316,7 +347,6 @@ def run_sharded(args, dev, rank, world, total=65536, alg_block=4096, vol_block=6
     unproj = torch.empty((vol_block, 32, S, S, S), dtype=torch.float32, device=dev)
     vols_out = torch.empty_like(vols)
     vkp_blk = torch.empty((vol_block, j, 3), dtype=torch.float32, device=dev)
-    ws3 = torch.empty(lib.mvx_unproject_workspace_bytes(vol_block, 4, 32, 96, 96) // 4 + 4, dtype=torch.float32, device=dev)
     ws4 = torch.empty(lib.mvx_soft_argmax_3d_workspace_bytes(vol_block, j, S, S, S) // 8 + 1, dtype=torch.float64, device=dev)
     rot = torch.eye(3, dtype=torch.float32, device=dev).reshape(1, 9).repeat(vol_block, 1).contiguous()
     step_mm = float(np.float32(side / (S - 1)))
@@ -345,22 +375,24 @@ def run_sharded(args, dev, rank, world, total=65536, alg_block=4096, vol_block=6
         for f0 in range(0, n_local, vol_block):
             nf = min(vol_block, n_local - f0)
             center = kp_all[f0:f0 + nf, synth.PELVIS_JOINT].contiguous()   # the pelvis the algebraic leg found
-            position = center - side / 2
+            position = (center - side / 2).contiguous()
             fail(lib.mvx_build_coord_volumes(_cabi.ptr(position), _cabi.ptr(center), _cabi.ptr(rot), nf, S, S, S, step_mm,
                                              step_mm, step_mm, 0, _cabi.ptr(coord), st))
             tm = t_unp if (timed and nf == vol_block) else None
             if tm is not None:
                 tm.__enter__()
-            rc = lib.mvx_unproject(_cabi.ptr(feats), _cabi.ptr(proj_hm), _cabi.ptr(coord), None, nf, 4, 32, 96, 96, S, S, S,
-                                   _cabi.AGG_SOFTMAX, _cabi.ptr(unproj), _cabi.ptr(ws3), ws3.numel() * 4, st)
+            rc = lib.mvx_unproject_grid(_cabi.ptr(feats), 1, _cabi.ptr(proj_hm), _cabi.ptr(position), _cabi.ptr(center),
+                                        _cabi.ptr(rot), step_mm, step_mm, step_mm, 0, None, nf, 4, 32, 96, 96, S, S, S,
+                                        _cabi.AGG_SOFTMAX, _cabi.ptr(unproj), None, 0, st)
             if tm is not None:
                 tm.__exit__()
             fail(rc)
             tm = t_k4 if (timed and nf == vol_block) else None
             if tm is not None:
                 tm.__enter__()
-            rc = lib.mvx_soft_argmax_3d(_cabi.ptr(vols), _cabi.ptr(coord), nf, j, S, S, S, 1.0, 1, _cabi.ptr(vkp_blk),
-                                        _cabi.ptr(vols_out), _cabi.ptr(ws4), ws4.numel() * 8, st)
+            rc = lib.mvx_soft_argmax_3d_grid(_cabi.ptr(vols), _cabi.ptr(position), _cabi.ptr(center), _cabi.ptr(rot), step_mm,
+                                             step_mm, step_mm, 0, nf, j, S, S, S, 1.0, 1, _cabi.ptr(vkp_blk),
+                                             _cabi.ptr(vols_out), _cabi.ptr(ws4), ws4.numel() * 8, st)
             if tm is not None:
                 tm.__exit__()
             fail(rc)
@@ -428,7 +460,7 @@ def run_sharded(args, dev, rank, world, total=65536, alg_block=4096, vol_block=6
     b3 = vol_block * (4 * 32 * 96 * 96 * 4 + n_vox * 12 + 32 * n_vox * 4)
     b4 = vol_block * (17 * n_vox * 4 * 2 + n_vox * 12)
     b1 = alg_block * v * j * (h * w * 4 * 2 + 8)
-    roof = {"bound": "hbm", "kernel": "unproject (channel-last copy + unproject_tile32<softmax>), %d-frame blocks" % vol_block,
+    roof = {"bound": "hbm", "kernel": "unproject_brick32<softmax> (channel-last maps, grid parameters), %d-frame blocks" % vol_block,
             "achieved": b3 / (t_unp.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": b3, "avg_launch_ms": t_unp.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
