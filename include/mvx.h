@@ -49,6 +49,7 @@ const char* mvx_last_error(void);
  * choice, so that tests and A/B timings can run the same inputs through the others.
  */
 #define MVX_SELECT_NO_UNPROJECT_BRICKS 1u /* mvx_unproject*: 8x8x8-voxel brick kernel (4 views x 32 channels) off */
+#define MVX_SELECT_NO_DLT_ROWS 2u         /* DLT entry points: 16-lanes-per-point kernel for small batches off */
 void mvx_set_kernel_selection(unsigned mask);
 
 /*

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmvx.so")
 MVX_OK, MVX_ERR_INVALID_ARGUMENT, MVX_ERR_HIP, MVX_ERR_WORKSPACE, MVX_ERR_UNSUPPORTED = range(5)
 AGG_SUM, AGG_CONF, AGG_MAX, AGG_SOFTMAX = range(4)
 SELECT_NO_UNPROJECT_BRICKS = 1
+SELECT_NO_DLT_ROWS = 2
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i64, _int, _f32, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t

@@ -15,6 +15,7 @@ namespace mvx {
 namespace {
 
 constexpr int kThreads = 128;
+constexpr int64_t kRowsMaxPoints = 2048;  // up to here the 16-lanes-per-point kernel is used (V <= 16)
 
 // GLUE: points are heatmap-pixel keypoints and conf the raw confidences; the kernel normalises the
 // confidences over the views (+1e-5), scales the keypoints to image pixels, stores both, and triangulates
@@ -84,6 +85,78 @@ __global__ __launch_bounds__(kThreads) void triangulate_dlt(const float* __restr
     out[idx * 3 + 2] = static_cast<float>(h[2] / h[3]);
 }
 
+// The same for small batches (a real-time stream triangulates 17 points per frame): 16 lanes per point, lane v
+// handling view v (V <= 16).  The confidence sum and the Gram matrix are reduced across the 16 lanes by DPP row
+// operations instead of a serial loop over the views, which is where a one-lane-per-point launch of 17 points spends
+// most of its time.  The Gram entries are the same exact float64 products summed in another order, so a result can
+// differ from the lane-per-point kernel's in the last float32 bit.
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;  // every lane of the 16-lane row holds the row's sum
+}
+
+template <bool GLUE>
+__global__ __launch_bounds__(256) void triangulate_dlt_rows(const float* __restrict__ proj, const float* __restrict__ points,
+                                                            const float* __restrict__ conf, int64_t n_points, int V, int J,
+                                                            float scale_x, float scale_y, float* __restrict__ points_out,
+                                                            float* __restrict__ conf_out, float* __restrict__ out) {
+    const int v = threadIdx.x & 15;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    // rows past the end and lanes past the last view compute on zeros (no early exit: the row reductions need
+    // every lane) and store nothing
+    const bool live = idx < n_points && v < V;
+    const int64_t b = idx < n_points ? idx / J : 0;
+    const int j = idx < n_points ? static_cast<int>(idx - b * J) : 0;
+    const int64_t pj = (b * V + (v < V ? v : 0)) * J + j;
+    const float* P = proj + (b * V + (v < V ? v : 0)) * 12;
+
+    float x = points[pj * 2 + 0], y = points[pj * 2 + 1];
+    float c = conf != nullptr ? conf[pj] : 1.0f;
+    if (GLUE) {
+        const double csum = row16_sum(live ? static_cast<double>(c) : 0.0);  // exact: float32 terms in float64
+        const float view_sum = static_cast<float>(csum);
+        c = c / view_sum + 1e-5f;
+        x = x * scale_x;
+        y = y * scale_y;
+        if (live) {
+            conf_out[pj] = c;
+            points_out[pj * 2 + 0] = x;
+            points_out[pj * 2 + 1] = y;
+        }
+    }
+    double r0[4], r1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // three separately rounded float32 operations (the library is built with -ffp-contract=off)
+        const float p2 = P[8 + k];
+        const float a0 = (p2 * x - P[k]) * c;
+        const float a1 = (p2 * y - P[4 + k]) * c;
+        r0[k] = live ? a0 : 0.0f;
+        r1[k] = live ? a1 : 0.0f;
+    }
+    double g[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = p; q < 4; ++q) g[p][q] = row16_sum(fma(r1[p], r1[q], r0[p] * r0[q]));
+#pragma unroll
+    for (int p = 1; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < p; ++q) g[p][q] = g[q][p];
+
+    double h[4];
+    smallest_eigenvector(g, h);  // every lane of the row solves the same matrix; lane 0 stores
+    if (v == 0 && idx < n_points) {
+        out[idx * 3 + 0] = static_cast<float>(h[0] / h[3]);
+        out[idx * 3 + 1] = static_cast<float>(h[1] / h[3]);
+        out[idx * 3 + 2] = static_cast<float>(h[2] / h[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void project_points(const float* __restrict__ proj, const float* __restrict__ pts,
                                                        int64_t n, int to_euclidean, float* __restrict__ out) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -118,6 +191,19 @@ int launch_dlt(bool glue, const float* proj, const float* points, const float* c
     MVX_REQUIRE(blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: %lld points beyond the launch limit", name,
                 (long long)n_points);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // few points (a real-time stream): 16 lanes per point, views in parallel; one lane per point cannot fill the
+    // chip below a few thousand points anyway
+    if (n_views <= 16 && n_points <= kRowsMaxPoints && !(kernel_selection() & MVX_SELECT_NO_DLT_ROWS)) {
+        const dim3 grid(static_cast<unsigned>((n_points + 15) / 16));
+        if (glue)
+            hipLaunchKernelGGL(triangulate_dlt_rows<true>, grid, dim3(256), 0, st, proj, points, conf, n_points, n_views,
+                               n_joints, sx, sy, points_out, conf_out, out);
+        else
+            hipLaunchKernelGGL(triangulate_dlt_rows<false>, grid, dim3(256), 0, st, proj, points, conf, n_points, n_views,
+                               n_joints, 1.0f, 1.0f, nullptr, nullptr, out);
+        MVX_CHECK_LAUNCH(name);
+        return MVX_OK;
+    }
     if (glue)
         hipLaunchKernelGGL(triangulate_dlt<true>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, st, proj,
                            points, conf, n_points, n_views, n_joints, sx, sy, points_out, conf_out, out);

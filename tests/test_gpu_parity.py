@@ -197,6 +197,42 @@ def test_dlt_recovers_exact_projections():
     assert np.array_equal(out_p, out[perm])
 
 
+@pytest.mark.parametrize("views", [2, 3, 4, 16])
+def test_dlt_small_batch_kernel_against_lane_per_point_kernel(views):
+    """Up to 2048 points the DLT runs with 16 lanes per point (views in parallel); beyond, with one lane per point.
+    Both on the same inputs: the glue outputs are bit-identical, the points agree to the last float32 bit or one
+    off (the float64 Gram sums run in another order) and both match the oracle."""
+    lib = _cabi.load()
+    frames = 7
+    case = synth.algebraic_case(90 + views, frames, views)
+    kp_hm = np.random.default_rng(views).uniform(5, 90, (frames, views, 17, 2)).astype(np.float32)
+    proj, conf, pts = to_dev(case["proj"]), to_dev(case["confidences"]), to_dev(kp_hm)
+    outs = {}
+    try:
+        for name, mask in (("rows", 0), ("lanes", _cabi.SELECT_NO_DLT_ROWS)):
+            lib.mvx_set_kernel_selection(mask)
+            kp_img = torch.empty_like(pts)
+            conf_n = torch.empty_like(conf)
+            kp3d = torch.empty((frames, 17, 3), device=dev())
+            rc = lib.mvx_algebraic_glue_dlt(_cabi.ptr(proj), _cabi.ptr(pts), _cabi.ptr(conf), frames, views, 17, 4.0, 4.0,
+                                            _cabi.ptr(kp_img), _cabi.ptr(conf_n), _cabi.ptr(kp3d), _cabi.stream(dev()))
+            assert rc == 0
+            plain = multiview.triangulate_batch_of_points(proj, kp_img, conf_n)
+            unweighted = multiview.triangulate_batch_of_points(proj, kp_img)
+            outs[name] = (kp_img, conf_n, kp3d, plain, unweighted)
+    finally:
+        lib.mvx_set_kernel_selection(0)
+    assert torch.equal(outs["rows"][0], outs["lanes"][0]) and torch.equal(outs["rows"][1], outs["lanes"][1])
+    for k in (2, 3, 4):
+        assert torch.allclose(outs["rows"][k], outs["lanes"][k], rtol=2e-7, atol=1e-4)
+    o2d, oconf = orc.algebraic_glue(kp_hm, case["confidences"], (384, 384), (96, 96))
+    assert np.array_equal(outs["rows"][0].cpu().numpy(), o2d) and np.array_equal(outs["rows"][1].cpu().numpy(), oconf)
+    want = orc.triangulate_batch_of_points(case["proj"], o2d, oconf)
+    for name in ("rows", "lanes"):
+        assert mm_close(outs[name][2].cpu().numpy(), want) and mm_close(outs[name][3].cpu().numpy(), want)
+        assert mm_close(outs[name][4].cpu().numpy(), orc.triangulate_batch_of_points(case["proj"], o2d))
+
+
 def test_dlt_empty_and_errors():
     out = multiview.triangulate_batch_of_points(torch.zeros(0, 4, 3, 4, device=dev()), torch.zeros(0, 4, 17, 2, device=dev()))
     assert out.shape == (0, 17, 3)
