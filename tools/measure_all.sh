@@ -11,13 +11,13 @@ run() {  # name, args...
   timeout -k 10 280 python3 -u bench.py "$@" > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || { echo "bench $name failed"; tail -5 "$OUT/bench_$name.err"; exit 1; }
   echo "bench $name ok"
 }
-run algebraic
+run default
 run algebraic_coords_only --no-writeback --no-cpu-baseline
 run volumetric --workload volumetric
-run stream16 --workload stream16
 run ransac --workload ransac
+MVX_BENCH_REHEARSAL=1 run rehearsal_2ranks_one_gpu --gpus 2 --steps 5
 cd /tmp && export TMPDIR=/tmp
 for W in algebraic volumetric ransac; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$W" -- python3 "$R/bench.py" --workload $W --steps 10 --no-cpu-baseline > "$OUT/prof_$W.log" 2>&1 || { echo "rocprof $W failed"; tail -5 "$OUT/prof_$W.log"; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$W" -- python3 "$R/bench.py" --workload $W --steps 10 --no-cpu-baseline --no-extra > "$OUT/prof_$W.log" 2>&1 || { echo "rocprof $W failed"; tail -5 "$OUT/prof_$W.log"; exit 1; }
   echo "rocprof $W ok"
 done
