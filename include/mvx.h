@@ -50,6 +50,7 @@ const char* mvx_last_error(void);
  */
 #define MVX_SELECT_NO_UNPROJECT_BRICKS 1u /* mvx_unproject*: 8x8x8-voxel brick kernel (4 views x 32 channels) off */
 #define MVX_SELECT_NO_DLT_ROWS 2u         /* DLT entry points: 16-lanes-per-point kernel for small batches off */
+#define MVX_SELECT_NO_SOFT_ARGMAX_RESIDENT 4u /* mvx_soft_argmax_3d*: one-read resident kernel off (three passes) */
 void mvx_set_kernel_selection(unsigned mask);
 
 /*
@@ -175,9 +176,13 @@ int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t
 /*
  * mvx_soft_argmax_3d with the voxel positions given by the parameters of a regular grid instead of a coordinate
  * volume: the grid VolumetricTriangulationNet.forward builds (mvn/models/triangulation.py:341-385) is evaluated inside
- * the kernel, in the float32 operation order of mvx_build_coord_volumes, so the result is bit-identical to
- * mvx_soft_argmax_3d fed the volume that mvx_build_coord_volumes writes for the same parameters, and the 12 bytes per
- * voxel of that volume are never read.  Grid arguments as in mvx_build_coord_volumes (s0, s1, s2 = sx, sy, sz).
+ * the kernel, and the 12 bytes per voxel of that volume are never read.  Without volumes_out, or without softmax,
+ * the positions are evaluated per voxel in the float32 operation order of mvx_build_coord_volumes and the result is
+ * bit-identical to mvx_soft_argmax_3d fed the volume that mvx_build_coord_volumes writes for the same parameters.
+ * With softmax and volumes_out (the one-read kernel) the expectation of the voxel index is taken in float64 and mapped
+ * through the grid once per volume: the positions it stands for are the exact ones, not their float32 roundings, so
+ * the coordinates differ from the tensor-fed result by less than the rounding of one position (about 2e-4 mm for
+ * positions of a few metres).  Grid arguments as in mvx_build_coord_volumes (s0, s1, s2 = sx, sy, sz).
  */
 int mvx_soft_argmax_3d_grid(const float* volumes, const float* position, const float* center, const float* rotation,
                             float step0, float step1, float step2, int swap_yz_flip, int64_t n_frames, int n_volumes,

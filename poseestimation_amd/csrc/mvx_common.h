@@ -44,17 +44,18 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ---- device side: wave64 reductions through DPP ----------------------------------------------
 // quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.
 // After the four steps every lane holds the reduction of its 16-lane row; the four rows are then
-// combined through readlane (wave-uniform result).
+// combined through readlane (wave-uniform result).  Every lane of these patterns has a valid source; bound_ctrl is
+// set only so that the compiler need not materialise the "old" operand (a v_mov of zero per DPP move).
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     unsigned long long b = __builtin_bit_cast(unsigned long long, v);
     int lo = static_cast<int>(b), hi = static_cast<int>(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     b = (static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo);
     return __builtin_bit_cast(double, b);
 }
@@ -68,6 +69,21 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
     return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
+// Division of small non-negative numbers by a runtime constant without the float-reciprocal sequence the compiler
+// emits for it: q = (mulhi(n, magic) + n) >> shift, exact for n < 2^31 (magic and shift from fast_divisor()).
+struct FastDiv {
+    unsigned magic, shift, divisor;
+};
+inline FastDiv fast_divisor(unsigned d) {
+    FastDiv f;
+    f.divisor = d;
+    f.shift = 0;
+    while ((1u << f.shift) < d) ++f.shift;
+    f.magic = static_cast<unsigned>((((1ull << f.shift) - d) << 32) / d + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv f) { return (__umulhi(n, f.magic) + n) >> f.shift; }
+
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<0xB1>(v));
     v = fmaxf(v, dpp_mov<0x4E>(v));
@@ -77,7 +93,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_movi(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 __device__ __forceinline__ int wave_min_i(int v) {
     v = min(v, dpp_movi<0xB1>(v));

@@ -1,5 +1,6 @@
 // Soft-argmax over voxel grids with world (or index) coordinates.
 //
+// Coordinates only, or no softmax: three passes.
 // Pass 1 (partial): every wave owns one contiguous segment of voxels of one frame, loads the segment's
 // coordinates once into registers and walks the frame's volumes (joints): wave max, exp, and the float64
 // sums (S, Sx, Sy, Sz) of that segment, written as one 40-byte record.  No LDS, no barriers; the coordinate
@@ -9,14 +10,21 @@
 // re-reads the volumes and writes exp(t - M) / S.  (Feeding the passes a few frames at a time so that the second
 // read would hit the Infinity Cache was measured slower than full-batch launches: small launches leave CUs idle.)
 //
+// Softmax with the normalised volumes wanted (what the volumetric model asks for): one kernel that reads every volume
+// once, soft_argmax_3d_resident below.  The three passes stay as the path for shapes it does not take and behind
+// MVX_SELECT_NO_SOFT_ARGMAX_RESIDENT.  Measured on MI355X, 64 frames x 17 volumes of 64^3: three passes 0.61 ms,
+// one read 0.47 ms (regular grid) / 0.54 ms (coordinate volume).  What made the one-read kernel pay, in the order
+// found: (1) no release fence on the hand-off -- it writes back the whole L2, which is full of streamed output --
+// but write-through stores of self-validating records; (2) the records of a team read by one lane each instead of
+// a serial loop of L2 round trips; (3) the share parked in LDS and written a step later, so no workgroup ever
+// waits for another on its critical path, with the record loads issued behind the arithmetic; (4) for regular
+// grids, moments of the voxel index (4 float64 operations per voxel instead of 17) mapped through the grid once
+// per volume.
+//
 // Coordinates come from a coordinate volume, from the voxel index (integrate_tensor_3d), or from the parameters of
 // a regular grid (grid_coords.h), in which case no coordinate bytes are read at all.
 //
-// Algorithmic bytes per frame: J*N*4 (volumes) + N*12 (coordinates) [+ J*N*4 written] + J*12 out; with the
-// write-back the volumes cross HBM a second time on the read side.  (A one-read variant -- teams of 4 to 16
-// workgroups holding a volume in registers as exp(t - own max), exchanging 40-byte records through memory and
-// rescaling on the way out -- was built, verified and measured slower on MI355X, 0.74 to 0.93 ms against 0.61 ms for
-// 64 frames: a compute unit alternates between its read phase and its write phase instead of overlapping them.)
+// Algorithmic bytes per frame: J*N*4 (volumes) + N*12 (coordinates) [+ J*N*4 written] + J*12 out.
 #include <stdlib.h>
 
 #include <mutex>
@@ -286,6 +294,260 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_normalize(const float
     }
 }
 
+// ---- one read per volume: resident workgroups that park a share of a volume in LDS ----------------------------
+// Softmax with the normalised volumes wanted.  A volume is cut into `team` shares of 512 threads x NV4 float4.  A
+// workgroup reduces a share from registers (max, then exp(t - own max) and the float64 sums), parks the exponentials in
+// LDS and publishes one 40-byte record; one step later, when the records of the whole team have long been published,
+// it combines them, rescales the parked share and writes it out.  Every volume crosses HBM once in each direction.
+// With a coordinate volume the sums are over the positions read from it.  With a regular grid (and in index space) the
+// sums are moments of the voxel index, four float64 operations per voxel, and the grid, affine in the index, is
+// applied to their quotient once per volume, in float64.
+//
+// The grid is no larger than what is resident at once, and workgroup w walks the shares w, w + G, w + 2G, ...  At any
+// time it has: the loads of its next share in flight (second register set), the share it reduces (first register
+// set), and the previous share parked in the other LDS buffer.  Nothing on the critical path waits for another
+// workgroup: the team's records are polled a full step after they were written.  G is a multiple of the team size, so
+// the members of a team are the same step of `team` different workgroups; a workgroup publishes the record of step
+// k before it polls step k - 1, and by induction over the steps nobody waits for a record that cannot come.  The
+// poll is bounded all the same (a fail-safe that raises a flag), never an endless spin.
+constexpr int kShareThreads = 512;
+constexpr int kTeamMax = 64;                    // one lane of a wave per member when the records are read
+constexpr size_t kFlagBytes = 256;              // head of the exchange area; word 0 = a member gave up waiting
+constexpr unsigned kTeamSpinLimit = 1u << 22;   // polls of about a microsecond: far beyond any real wait
+
+// Coordinates of the four voxels i..i+3 (i a multiple of 4) from a frame's coordinate volume.
+__device__ __forceinline__ void row_coords4(const float* __restrict__ coord_frame, unsigned i, float (&cx)[4],
+                                            float (&cy)[4], float (&cz)[4]) {
+    const float4* p = reinterpret_cast<const float4*>(coord_frame + static_cast<size_t>(i) * 3);
+    const float4 a = p[0], b4 = p[1], c = p[2];
+    cx[0] = a.x; cy[0] = a.y; cz[0] = a.z;
+    cx[1] = a.w; cy[1] = b4.x; cz[1] = b4.y;
+    cx[2] = b4.z; cy[2] = b4.w; cz[2] = c.x;
+    cx[3] = c.y; cy[3] = c.z; cz[3] = c.w;
+}
+
+// flags[0] = set if a member gave up waiting.  records[volume][member] = (max, S, Sx, Sy, Sz) of the member's share,
+// sums relative to its own max; all zero bits at launch (hipMemsetAsync ahead of it), never zero once published.
+// Dynamic LDS: two buffers of 512 x NV4 float4.
+template <int NV4, int SRC>
+__global__ __launch_bounds__(kShareThreads, 4) void soft_argmax_3d_resident(
+    const float* __restrict__ vol, CoordSource coord, int J, unsigned n_vox, Grid3 g, FastDiv d_sy, FastDiv d_sz, int team,
+    unsigned n_shares, float mult, unsigned* __restrict__ flags, double* __restrict__ records, float* __restrict__ out,
+    float* __restrict__ vol_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    vec4f* parked = reinterpret_cast<vec4f*>(smem);  // [2][NV4][512]
+    __shared__ float s_max[kShareThreads / 64];
+    __shared__ double s_sum[kShareThreads / 16][4];  // per 16-lane row: S, Sy, Sx, Sz
+    __shared__ float s_scale[2];  // per LDS buffer: two write-outs can follow each other without a barrier between
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned share_vox = n_vox / static_cast<unsigned>(team);
+
+    auto share_base = [&](unsigned item) {  // element offset of a share in the batch of volumes
+        const unsigned volume = item / static_cast<unsigned>(team);
+        const unsigned member = item - volume * static_cast<unsigned>(team);
+        return static_cast<size_t>(volume) * n_vox + static_cast<size_t>(member) * share_vox;
+    };
+    auto load_share = [&](unsigned item, vec4f (&v)[NV4]) {
+        const float* src = vol + share_base(item);
+#pragma unroll
+        for (int k = 0; k < NV4; ++k)
+            v[k] = __builtin_nontemporal_load(reinterpret_cast<const vec4f*>(src + (k * kShareThreads + tid) * 4));
+    };
+    // Lane i of wave 0 reads the record of member i of a share's team with agent-scope loads (served by L2, never by
+    // a stale L1 line).  A record is complete when none of its words is zero.
+    long long w[kRecord];
+    auto fetch_records = [&](unsigned item) {
+        const unsigned volume = item / static_cast<unsigned>(team);
+        const long long* theirs = reinterpret_cast<const long long*>(
+            records + (static_cast<size_t>(volume) * team + min(lane, team - 1)) * kRecord);
+#pragma unroll
+        for (int i = 0; i < kRecord; ++i)
+            w[i] = __hip_atomic_load(theirs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // reduces a share, parks e = exp(t - own max) in LDS buffer `buf` and publishes its record; on the way, wave 0
+    // fetches the records of the share written next (`pending`, published a step ago) behind the arithmetic
+    auto reduce_share = [&](unsigned item, vec4f (&v)[NV4], int buf, bool has_pending, unsigned pending) {
+        const unsigned volume = item / static_cast<unsigned>(team);
+        const unsigned member = item - volume * static_cast<unsigned>(team);
+        const int64_t b = volume / static_cast<unsigned>(J);
+        const unsigned first = member * share_vox;
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) {
+            v[k] *= mult;
+            m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+        }
+        m = wave_max(m);
+        if (lane == 0) s_max[wave] = m;
+        __syncthreads();  // also: every wave has finished reading this LDS buffer (the write-out two steps ago)
+        m = s_max[0];
+#pragma unroll
+        for (int i = 1; i < kShareThreads / 64; ++i) m = fmaxf(m, s_max[i]);
+        const float mref = (m == -INFINITY) ? 0.0f : m;  // a share holding only -inf contributes nothing
+        if (wave == 0 && has_pending) fetch_records(pending);
+
+        const float* coord_frame = SRC == 0 ? coord.volume + static_cast<size_t>(b) * n_vox * 3 : nullptr;
+        double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) {
+            const unsigned i = first + (k * kShareThreads + tid) * 4;
+            const vec4f d = (v[k] - mref) * 1.44269504088896340736f;  // exp_neg, with the packed subtract and multiply
+            vec4f e;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) e[l] = __builtin_amdgcn_exp2f(d[l]);
+            if (SRC == 0) {
+                float cx[4], cy[4], cz[4];
+                row_coords4(coord_frame, i, cx, cy, cz);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    const double ed = e[l];
+                    s += ed;
+                    sx = fma(ed, static_cast<double>(cx[l]), sx);
+                    sy = fma(ed, static_cast<double>(cy[l]), sy);
+                    sz = fma(ed, static_cast<double>(cz[l]), sz);
+                }
+            } else {
+                // four voxels (x, y, z..z+3) of one grid row: moments of the voxel index
+                const unsigned row = fast_div(i, d_sz), z = i - row * d_sz.divisor;
+                const unsigned x = fast_div(row, d_sy), y = row - x * d_sy.divisor;
+                const double e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                const double q = (e0 + e1) + (e2 + e3);
+                s += q;
+                sx = fma(q, static_cast<double>(x), sx);
+                sy = fma(q, static_cast<double>(y), sy);
+                sz = fma(q, static_cast<double>(z), sz) + fma(3.0, e3, fma(2.0, e2, e1));
+            }
+            parked[(buf * NV4 + k) * kShareThreads + tid] = e;
+        }
+        // The four sums are reduced together.  Two quad exchanges hand each lane one quantity of its quad (lane & 3 =
+        // 0, 1, 2, 3 holds S, Sy, Sx, Sz), two row shifts leave the totals of a 16-lane row in its lanes 12 to 15,
+        // and those go to LDS: 32 row totals per quantity, which four lanes of wave 0 add up after the barrier.
+        {
+            const bool odd = lane & 1, upper = lane & 2;
+            const double a0 = (odd ? sy : s) + dpp_mov<0xB1>(odd ? s : sy);
+            const double a1 = (odd ? sz : sx) + dpp_mov<0xB1>(odd ? sx : sz);
+            double t = (upper ? a1 : a0) + dpp_mov<0x4E>(upper ? a0 : a1);
+            t += dpp_mov<0x114>(t);  // row_shr:4, zero shifted in
+            t += dpp_mov<0x118>(t);  // row_shr:8
+            if ((lane & 12) == 12) s_sum[wave * 4 + (lane >> 4)][lane & 3] = t;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double total = 0.0;
+            for (int i = 0; i < kShareThreads / 16; ++i) total += s_sum[i][lane & 3];
+            // Publish: agent-scope (write-through) 8-byte stores, one word per lane; +0.0, the one value that is
+            // all zero bits, goes out as the smallest denormal, so no published word is zero.  There is no flag,
+            // nothing to wait for on the writing side, and no cache write-back or invalidate: a release fence would
+            // flush the whole L2 of the XCD, which is full of the volumes being streamed out.
+            if (lane < 4) {
+                long long* mine =
+                    reinterpret_cast<long long*>(records + (static_cast<size_t>(volume) * team + member) * kRecord);
+                const int word = lane == 0 ? 1 : (lane == 1 ? 3 : (lane == 2 ? 2 : 4));  // S, Sy, Sx, Sz
+                const long long bits = __double_as_longlong(total);
+                __hip_atomic_store(mine + word, bits != 0 ? bits : 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    const long long mbits = __double_as_longlong(static_cast<double>(m));
+                    __hip_atomic_store(mine, mbits != 0 ? mbits : 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
+    // combines the records of a share's team and writes the share parked in LDS buffer `buf`
+    auto write_share = [&](unsigned item, int buf, bool prefetched) {
+        const unsigned volume = item / static_cast<unsigned>(team);
+        const unsigned member = item - volume * static_cast<unsigned>(team);
+        if (wave == 0) {
+            // the records were fetched during the reduction of the next share; fetch again until all are complete
+            unsigned spins = 0;
+            if (!prefetched) fetch_records(item);
+            while (true) {
+                bool ready = true;
+#pragma unroll
+                for (int i = 0; i < kRecord; ++i) ready = ready && w[i] != 0;
+                if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
+                if (++spins > kTeamSpinLimit) {  // gave up: raise the flag and let the share come out as NaN
+                    if (lane == 0) __hip_atomic_store(&flags[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w[0] = __double_as_longlong(__builtin_nan(""));
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+                fetch_records(item);
+            }
+            const bool counts = lane < team;  // the lanes beyond the team re-read its last record
+            const double rm = counts ? __longlong_as_double(w[0]) : -INFINITY;
+            const double rs = counts ? __longlong_as_double(w[1]) : 0.0;
+            const double rx = counts ? __longlong_as_double(w[2]) : 0.0;
+            const double ry = counts ? __longlong_as_double(w[3]) : 0.0;
+            const double rz = counts ? __longlong_as_double(w[4]) : 0.0;
+            const double M = static_cast<double>(wave_max(static_cast<float>(rm)));  // the maxima are float32 values
+            const double wgt = exp(rm - M);  // a share of -inf, and a lane beyond the team, has weight 0
+            const double S = wave_sum(rs * wgt);
+            const double Sx = wave_sum(rx * wgt), Sy = wave_sum(ry * wgt), Sz = wave_sum(rz * wgt);
+            const double own = __shfl(wgt, static_cast<int>(member));
+            if (lane == 0) {
+                if (member == 0) {
+                    double ex = Sx / S, ey = Sy / S, ez = Sz / S;
+                    if (SRC == 2) {
+                        // expectation of the voxel index -> world position: the grid is affine in the index
+                        const GridSpec& gs = coord.grid;
+                        const size_t b = volume / static_cast<unsigned>(J);
+                        const double i1 = gs.swap_yz_flip ? ez : ey;
+                        const double i2 = gs.swap_yz_flip ? static_cast<double>(g.sy - 1) - ey : ez;
+                        const double c0 = gs.center[b * 3 + 0], c1 = gs.center[b * 3 + 1], c2 = gs.center[b * 3 + 2];
+                        const double d0 = (gs.position[b * 3 + 0] + static_cast<double>(gs.step0) * ex) - c0;
+                        const double d1 = (gs.position[b * 3 + 1] + static_cast<double>(gs.step1) * i1) - c1;
+                        const double d2 = (gs.position[b * 3 + 2] + static_cast<double>(gs.step2) * i2) - c2;
+                        const float* r = gs.rotation + b * 9;
+                        ex = fma(r[2], d2, fma(r[1], d1, r[0] * d0)) + c0;
+                        ey = fma(r[5], d2, fma(r[4], d1, r[3] * d0)) + c1;
+                        ez = fma(r[8], d2, fma(r[7], d1, r[6] * d0)) + c2;
+                    }
+                    out[static_cast<size_t>(volume) * 3 + 0] = static_cast<float>(ex);
+                    out[static_cast<size_t>(volume) * 3 + 1] = static_cast<float>(ey);
+                    out[static_cast<size_t>(volume) * 3 + 2] = static_cast<float>(ez);
+                }
+                s_scale[buf] = static_cast<float>(own / S);
+            }
+        }
+        __syncthreads();
+        const float scale = s_scale[buf];
+        float* dst = vol_out + share_base(item);
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) {
+            const vec4f p = parked[(buf * NV4 + k) * kShareThreads + tid] * scale;
+            __builtin_nontemporal_store(p, reinterpret_cast<vec4f*>(dst + (k * kShareThreads + tid) * 4));
+        }
+    };
+
+    const unsigned G = gridDim.x;
+    vec4f a[NV4], c[NV4];
+    unsigned item = blockIdx.x;
+    if (item >= n_shares) return;  // (the host launches no more workgroups than shares)
+    load_share(item, a);
+    if (item + G < n_shares) load_share(item + G, c);
+    bool first_step = true;
+    while (true) {
+        // even step: share `item` from register set a into LDS buffer 0; the share of the step before leaves buffer 1
+        reduce_share(item, a, 0, !first_step, item - G);
+        if (item + 2 * G < n_shares) load_share(item + 2 * G, a);
+        if (!first_step) write_share(item - G, 1, true);
+        first_step = false;
+        if (item + G >= n_shares) {
+            write_share(item, 0, false);
+            break;
+        }
+        // odd step: share item + G from register set c into LDS buffer 1; the even step's share leaves buffer 0
+        reduce_share(item + G, c, 1, true, item);
+        if (item + 3 * G < n_shares) load_share(item + 3 * G, c);
+        write_share(item, 0, true);
+        if (item + 2 * G >= n_shares) {
+            write_share(item + G, 1, false);
+            break;
+        }
+        item += 2 * G;
+    }
+}
+
 // Voxels per wave segment for a batch: long segments amortise the per-joint wave reductions, short ones keep
 // every CU busy when there are few frames.
 int pick_nv(int64_t n_frames, int64_t n_vox) {
@@ -306,6 +568,42 @@ extern "C" size_t mvx_soft_argmax_3d_workspace_bytes(int64_t n_frames, int n_vol
 
 namespace mvx {
 namespace {
+constexpr size_t resident_lds_bytes(int nv4) { return static_cast<size_t>(2) * nv4 * kShareThreads * 16; }
+
+// Workgroups of soft_argmax_3d_resident<NV4, SRC> that the current device holds at once (cached per device):
+// compute units x workgroups per compute unit as the runtime reports them, the latter capped at two.
+int resident_workgroups(int nv4, int source) {
+    static std::mutex mutex;
+    static int cached[64][3][3];  // [device][log2 nv4][source], 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    const int slot = nv4 == 4 ? 2 : (nv4 == 2 ? 1 : 0);
+    std::lock_guard<std::mutex> lock(mutex);
+    if (cached[dev][slot][source] == 0) {
+        int per_cu = 0, cus = 0;
+        hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+#define MVX_OCCUPANCY(NV4, SRC)                                                                                    \
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, soft_argmax_3d_resident<NV4, SRC>, kShareThreads, \
+                                                     resident_lds_bytes(NV4))
+#define MVX_OCCUPANCY_SRC(NV4)                  \
+    if (source == 0) MVX_OCCUPANCY(NV4, 0);     \
+    else if (source == 1) MVX_OCCUPANCY(NV4, 1); \
+    else MVX_OCCUPANCY(NV4, 2)
+        if (e == hipSuccess) {
+            switch (nv4) {
+                case 1: MVX_OCCUPANCY_SRC(1); break;
+                case 2: MVX_OCCUPANCY_SRC(2); break;
+                default: MVX_OCCUPANCY_SRC(4); break;
+            }
+        }
+#undef MVX_OCCUPANCY_SRC
+#undef MVX_OCCUPANCY
+        if (e != hipSuccess || per_cu < 1 || cus < 1) return 0;
+        cached[dev][slot][source] = cus * (per_cu > 2 ? 2 : per_cu);
+    }
+    return cached[dev][slot][source];
+}
+
 // `index_space`: the expectation of the voxel index (integrate_tensor_3d) rather than of a position.
 int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool index_space, int64_t n_frames, int n_volumes,
                        int sx, int sy, int sz, float multiplier, int softmax, float* out, float* volumes_out,
@@ -335,6 +633,55 @@ int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool inde
     const int mode = softmax ? 0 : (index_space ? 2 : 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partial = static_cast<double*>(workspace);
+
+    // softmax with the normalised volumes wanted: one kernel, one read of each volume, resident workgroups
+    if (softmax && volumes_out != nullptr && vec && sz % 4 == 0 &&
+        !(kernel_selection() & MVX_SELECT_NO_SOFT_ARGMAX_RESIDENT)) {
+        // a share is NV4 float4 per lane of 512 threads: the largest NV4 of 4, 2, 1 that cuts the volume into 1 to 64
+        const int64_t lane_span = static_cast<int64_t>(kShareThreads) * 4;
+        int nv4 = 0, team = 0;
+        for (int cand = 4; cand >= 1 && nv4 == 0; cand >>= 1) {
+            const int64_t share = lane_span * cand;
+            if (n_vox % share == 0 && n_vox / share <= kTeamMax) {
+                nv4 = cand;
+                team = static_cast<int>(n_vox / share);
+            }
+        }
+        const int64_t n_vol_total = n_frames * n_volumes;
+        const int source = coord.volume != nullptr ? 0 : (coord.has_grid ? 2 : 1);
+        const int resident = nv4 != 0 ? resident_workgroups(nv4, source) : 0;
+        const int64_t n_shares = n_vol_total * team;
+        int64_t grid_size = resident / (team > 0 ? team : 1) * team;  // whole teams only
+        if (grid_size > n_shares) grid_size = n_shares;
+        // workspace: 256 bytes of flags, then one record per share; all of it zero when the kernel starts
+        const size_t exchange_bytes = kFlagBytes + static_cast<size_t>(n_shares) * kRecord * sizeof(double);
+        if (nv4 != 0 && grid_size >= team && n_shares < (1LL << 31) && exchange_bytes <= workspace_bytes) {
+            unsigned* flags = static_cast<unsigned*>(workspace);
+            double* records = reinterpret_cast<double*>(static_cast<unsigned char*>(workspace) + kFlagBytes);
+            const hipError_t e = hipMemsetAsync(workspace, 0, exchange_bytes, st);
+            MVX_REQUIRE(e == hipSuccess, MVX_ERR_HIP, "mvx_soft_argmax_3d: clearing the team records failed: %s",
+                        hipGetErrorString(e));
+            const dim3 grid(static_cast<unsigned>(grid_size)), block(kShareThreads);
+            const FastDiv d_sy = fast_divisor(static_cast<unsigned>(sy)), d_sz = fast_divisor(static_cast<unsigned>(sz));
+#define MVX_LAUNCH_RESIDENT_SRC(NV4, SRC)                                                                            \
+    hipLaunchKernelGGL((soft_argmax_3d_resident<NV4, SRC>), grid, block, resident_lds_bytes(NV4), st, volumes, coord, n_volumes, \
+                       static_cast<unsigned>(n_vox), g, d_sy, d_sz, team, static_cast<unsigned>(n_shares), multiplier, flags,    \
+                       records, out, volumes_out)
+#define MVX_LAUNCH_RESIDENT(NV4)                               \
+    if (source == 0) MVX_LAUNCH_RESIDENT_SRC(NV4, 0);          \
+    else if (source == 1) MVX_LAUNCH_RESIDENT_SRC(NV4, 1);     \
+    else MVX_LAUNCH_RESIDENT_SRC(NV4, 2)
+            switch (nv4) {
+                case 1: MVX_LAUNCH_RESIDENT(1); break;
+                case 2: MVX_LAUNCH_RESIDENT(2); break;
+                default: MVX_LAUNCH_RESIDENT(4); break;
+            }
+#undef MVX_LAUNCH_RESIDENT
+#undef MVX_LAUNCH_RESIDENT_SRC
+            MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (resident)");
+            return MVX_OK;
+        }
+    }
 
     const int64_t n_total = n_frames * n_volumes * n_vox;
     const int64_t norm_blocks = (n_total + kThreads * 4 - 1) / (kThreads * 4);

@@ -512,21 +512,6 @@ struct BrickShared {
     int bad;              // some lane's taps lie outside the patches
 };
 
-// Division of small non-negative numbers by a runtime constant without the float-reciprocal sequence the compiler
-// emits for it: q = (mulhi(n, magic) + n) >> shift, exact for n < 2^31 (magic and shift from fast_divisor()).
-struct FastDiv {
-    unsigned magic, shift, divisor;
-};
-inline FastDiv fast_divisor(unsigned d) {
-    FastDiv f;
-    f.divisor = d;
-    f.shift = 0;
-    while ((1u << f.shift) < d) ++f.shift;
-    f.magic = static_cast<unsigned>((((1ull << f.shift) - d) << 32) / d + 1);
-    return f;
-}
-__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv f) { return (__umulhi(n, f.magic) + n) >> f.shift; }
-
 #ifdef MVX_BRICK_STATS  // development builds only (tools/brick_stats.hip)
 __device__ unsigned brick_stats[4];  // bricks, bricks on the direct path, bricks whose patches do not fit, max rows
 __device__ unsigned long long brick_phase[8];  // summed s_memtime deltas of wave 0 between the kernel's phases

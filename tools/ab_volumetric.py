@@ -45,7 +45,7 @@ def timeit(fn, n=20):
     return float(np.median(ts))
 
 
-for name, mask in (("default kernels", 0), ("without the brick kernel", 1)):
+for name, mask in (("default kernels", 0), ("without the brick and resident kernels", 5)):
     lib.mvx_set_kernel_selection(mask)
     print("--", name)
     print("  unproject NCHW, coordinate volume   %.3f ms" % timeit(lambda: op.unproject_heatmaps(feats, proj, coord, "softmax")))
