@@ -75,8 +75,8 @@ class EventTimer:
 KERNEL_SOURCES = {   # the files a kernel is compiled from: a counter record is valid for exactly these bytes
     "soft_argmax_2d_reg<9>": ("soft_argmax_2d.hip", "mvx_common.h"),
     "heatmap_argmax<9>": ("ransac.hip", "mvx_common.h"),
-    "unproject": ("unproject.hip", "mvx_common.h"),
-    "soft_argmax_3d": ("soft_argmax_3d.hip", "mvx_common.h"),
+    "unproject": ("unproject.hip", "grid_coords.h", "mvx_common.h"),
+    "soft_argmax_3d": ("soft_argmax_3d.hip", "grid_coords.h", "mvx_common.h"),
 }
 
 
@@ -305,9 +305,14 @@ def run_volumetric(args, dev, rank, world, frames=64):
             "achieved": b3 / (k3.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": b3, "avg_launch_ms": k3.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"], roof["traffic_source"] = measured_traffic("unproject", {"frames": frames, "views": 4, "method": "softmax"})
+    roof["traffic"], roof["traffic_source"] = measured_traffic(
+        "unproject", {"frames": frames, "views": 4, "method": "softmax", "maps": "channel-last", "coordinates": "grid parameters"})
+    t4, t4_source = measured_traffic(
+        "soft_argmax_3d", {"frames": frames, "volumes": 17, "grid": 64, "write_volumes": True, "coordinates": "grid parameters"})
     extra = {"soft_argmax_3d_ms": k4.mean_ms(), "soft_argmax_3d_GBps": b4 / (k4.mean_ms() * 1e-3) / 1e9,
              "soft_argmax_3d_frac_of_hbm_peak": b4 / (k4.mean_ms() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "soft_argmax_3d_traffic": t4, "soft_argmax_3d_traffic_source": t4_source,
+             "soft_argmax_3d_algorithmic_bytes_per_launch": b4,
              "unproject_plain_api_ms": api.mean_ms(),
              "unproject_plain_api_note": "maps [view][channel][h][w] (layout copy inside) and an untagged coordinate tensor",
              "max_abs_error_unproject_vs_float64_torch": err_u, "max_abs_error_keypoints_vs_float64_torch_mm": err_k}

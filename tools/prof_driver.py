@@ -1,6 +1,6 @@
 """Development tool: launches one kernel family a few times so that a profiler sees little else.
 
-    python3 tools/prof_driver.py k1|k2|k3|k4|k4w [launches]
+    python3 tools/prof_driver.py k1|k2|k3|k4|k4w|k3m|k4m [launches]     (k3m / k4m: as the volumetric model calls them)
 """
 import os
 import sys
@@ -46,5 +46,19 @@ elif which in ("k3", "k4", "k4w"):
                                   case["vol_confidences"])
         else:
             op.integrate_tensor_3d_with_coordinates(case["volumes"], case["coord_volumes"], return_volumes=(which == "k4w"))
+elif which in ("k3m", "k4m"):
+    import bench
+    from poseestimation_amd import synth
+    frames = int(os.environ.get("FRAMES", "64"))
+    case = synth.device_volumetric_case(9, frames, 4, dev)
+    coord = bench.library_grid(torch.from_numpy(case["base_points"]), dev)
+    feats = case["features"]
+    b, v, c, h, w = feats.shape
+    fcl = feats.view(b * v, c, h, w).contiguous(memory_format=torch.channels_last).view(b, v, c, h, w)
+    for _ in range(n):
+        if which == "k3m":
+            op.unproject_heatmaps(fcl, case["proj"], coord, "softmax", case["vol_confidences"])
+        else:
+            op.integrate_tensor_3d_with_coordinates(case["volumes"], coord, True)
 torch.cuda.synchronize()
 print("done", which)
