@@ -83,3 +83,31 @@ for V in (4, 16):
     for _ in range(2000):
         torch.cuda.synchronize()
     print("  empty synchronize: %.1f us" % ((time.perf_counter() - t0) / 2000 * 1e6))
+
+# floor: one trivial launch (a 1-voxel coordinate volume) + synchronize, and two of them
+one = torch.zeros(3, device=dev)
+rot1 = torch.eye(3, device=dev).reshape(1, 9).contiguous()
+out1 = torch.empty(3, device=dev)
+st = _cabi.stream(dev)
+
+
+def tiny():
+    lib.mvx_build_coord_volumes(_cabi.ptr(one), _cabi.ptr(one), _cabi.ptr(rot1), 1, 1, 1, 1, 1.0, 1.0, 1.0, 0, _cabi.ptr(out1), st)
+
+
+def tiny2():
+    tiny()
+    tiny()
+
+
+for name, fn in (("one trivial launch", tiny), ("two trivial launches", tiny2)):
+    for _ in range(100):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(2000):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    print("  %s + synchronize: p50 %.1f us p99 %.1f us" % (name, np.percentile(ts, 50) * 1e6, np.percentile(ts, 99) * 1e6))
