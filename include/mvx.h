@@ -51,6 +51,9 @@ const char* mvx_last_error(void);
 #define MVX_SELECT_NO_UNPROJECT_BRICKS 1u /* mvx_unproject*: 8x8x8-voxel brick kernel (4 views x 32 channels) off */
 #define MVX_SELECT_NO_DLT_ROWS 2u         /* DLT entry points: 16-lanes-per-point kernel for small batches off */
 #define MVX_SELECT_NO_SOFT_ARGMAX_RESIDENT 4u /* mvx_soft_argmax_3d*: one-read resident kernel off (three passes) */
+#define MVX_SELECT_SOFT_ARGMAX_HELP_ALWAYS 8u /* one-read kernel: every workgroup recomputes its team-mates' partial
+                                                 sums itself instead of reading them (the path it otherwise takes
+                                                 only for a team-mate that is not resident) */
 void mvx_set_kernel_selection(unsigned mask);
 
 /*

@@ -17,6 +17,7 @@ AGG_SUM, AGG_CONF, AGG_MAX, AGG_SOFTMAX = range(4)
 SELECT_NO_UNPROJECT_BRICKS = 1
 SELECT_NO_DLT_ROWS = 2
 SELECT_NO_SOFT_ARGMAX_RESIDENT = 4
+SELECT_SOFT_ARGMAX_HELP_ALWAYS = 8
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i64, _int, _f32, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t

@@ -307,13 +307,13 @@ __global__ __launch_bounds__(kThreads) void soft_argmax_3d_normalize(const float
 // time it has: the loads of its next share in flight (second register set), the share it reduces (first register
 // set), and the previous share parked in the other LDS buffer.  Nothing on the critical path waits for another
 // workgroup: the team's records are polled a full step after they were written.  G is a multiple of the team size, so
-// the members of a team are the same step of `team` different workgroups; a workgroup publishes the record of step
-// k before it polls step k - 1, and by induction over the steps nobody waits for a record that cannot come.  The
-// poll is bounded all the same (a fail-safe that raises a flag), never an endless spin.
+// the members of a team are the same step of `team` different workgroups, and in the normal case -- the whole grid
+// resident -- every record is there when it is polled.  No workgroup depends on that: the poll is bounded, and a
+// record that has not arrived by then (a team-mate whose slot another kernel or process holds) is recomputed from
+// memory by the workgroup that needs it.  Progress never hangs on co-residency; only speed does.
 constexpr int kShareThreads = 512;
 constexpr int kTeamMax = 64;                    // one lane of a wave per member when the records are read
-constexpr size_t kFlagBytes = 256;              // head of the exchange area; word 0 = a member gave up waiting
-constexpr unsigned kTeamSpinLimit = 1u << 22;   // polls of about a microsecond: far beyond any real wait
+constexpr unsigned kTeamPolls = 64;             // polls (a few microseconds each) before a workgroup helps itself
 
 // Coordinates of the four voxels i..i+3 (i a multiple of 4) from a frame's coordinate volume.
 __device__ __forceinline__ void row_coords4(const float* __restrict__ coord_frame, unsigned i, float (&cx)[4],
@@ -326,13 +326,76 @@ __device__ __forceinline__ void row_coords4(const float* __restrict__ coord_fram
     cx[3] = c.y; cy[3] = c.z; cz[3] = c.w;
 }
 
-// flags[0] = set if a member gave up waiting.  records[volume][member] = (max, S, Sx, Sy, Sz) of the member's share,
+// Adds the four voxels i..i+3 of a share (exponentials e) to its sums: over the positions of a coordinate volume
+// (SRC 0), or as moments of the voxel index (x, y, z..z+3 of one grid row).
+template <int SRC>
+__device__ __forceinline__ void add_moments(const float* __restrict__ coord_frame, unsigned i, const vec4f& e,
+                                            FastDiv d_sy, FastDiv d_sz, double& s, double& sx, double& sy,
+                                            double& sz) {
+    if (SRC == 0) {
+        float cx[4], cy[4], cz[4];
+        row_coords4(coord_frame, i, cx, cy, cz);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const double ed = e[l];
+            s += ed;
+            sx = fma(ed, static_cast<double>(cx[l]), sx);
+            sy = fma(ed, static_cast<double>(cy[l]), sy);
+            sz = fma(ed, static_cast<double>(cz[l]), sz);
+        }
+    } else {
+        const unsigned row = fast_div(i, d_sz), z = i - row * d_sz.divisor;
+        const unsigned x = fast_div(row, d_sy), y = row - x * d_sy.divisor;
+        const double e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+        const double q = (e0 + e1) + (e2 + e3);
+        s += q;
+        sx = fma(q, static_cast<double>(x), sx);
+        sy = fma(q, static_cast<double>(y), sy);
+        sz = fma(q, static_cast<double>(z), sz) + fma(3.0, e3, fma(2.0, e2, e1));
+    }
+}
+
+// The record (max, S, Sx, Sy, Sz) of the share of `share_vox` voxels starting at voxel `first` of a volume, computed
+// by the calling wave alone from memory (two passes, few registers): what a workgroup falls back on when a
+// team-mate's record does not arrive, so that no workgroup ever depends on another one being resident.  Kept out of
+// line: it is cold, and inlined it costs the hot loop registers.  The sums are taken in another order than the
+// owner's (their last bits differ).
+template <int SRC>
+__device__ __noinline__ void share_record_by_one_wave(const float* __restrict__ volume, const float* __restrict__ coord_frame,
+                                                      unsigned first, unsigned share_vox, float mult, FastDiv d_sy,
+                                                      FastDiv d_sz, double* __restrict__ rec) {
+    const unsigned lane = threadIdx.x & 63u;
+    const float* src = volume + first;
+    float m = -INFINITY;
+    for (unsigned i = lane * 4; i < share_vox; i += 64 * 4) {
+        const vec4f t = *reinterpret_cast<const vec4f*>(src + i) * mult;
+        m = fmaxf(m, fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+    }
+    m = wave_max(m);
+    const float mref = (m == -INFINITY) ? 0.0f : m;
+    double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    for (unsigned i = lane * 4; i < share_vox; i += 64 * 4) {
+        const vec4f t = *reinterpret_cast<const vec4f*>(src + i) * mult;
+        const vec4f d = (t - mref) * 1.44269504088896340736f;
+        vec4f e;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) e[l] = __builtin_amdgcn_exp2f(d[l]);
+        add_moments<SRC>(coord_frame, first + i, e, d_sy, d_sz, s, sx, sy, sz);
+    }
+    rec[0] = static_cast<double>(m);
+    rec[1] = wave_sum(s);
+    rec[2] = wave_sum(sx);
+    rec[3] = wave_sum(sy);
+    rec[4] = wave_sum(sz);
+}
+
+// records[volume][member] = (max, S, Sx, Sy, Sz) of the member's share,
 // sums relative to its own max; all zero bits at launch (hipMemsetAsync ahead of it), never zero once published.
 // Dynamic LDS: two buffers of 512 x NV4 float4.
 template <int NV4, int SRC>
 __global__ __launch_bounds__(kShareThreads, 4) void soft_argmax_3d_resident(
     const float* __restrict__ vol, CoordSource coord, int J, unsigned n_vox, Grid3 g, FastDiv d_sy, FastDiv d_sz, int team,
-    unsigned n_shares, float mult, unsigned* __restrict__ flags, double* __restrict__ records, float* __restrict__ out,
+    unsigned n_shares, float mult, int help_always, double* __restrict__ records, float* __restrict__ out,
     float* __restrict__ vol_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     vec4f* parked = reinterpret_cast<vec4f*>(smem);  // [2][NV4][512]
@@ -395,28 +458,7 @@ __global__ __launch_bounds__(kShareThreads, 4) void soft_argmax_3d_resident(
             vec4f e;
 #pragma unroll
             for (int l = 0; l < 4; ++l) e[l] = __builtin_amdgcn_exp2f(d[l]);
-            if (SRC == 0) {
-                float cx[4], cy[4], cz[4];
-                row_coords4(coord_frame, i, cx, cy, cz);
-#pragma unroll
-                for (int l = 0; l < 4; ++l) {
-                    const double ed = e[l];
-                    s += ed;
-                    sx = fma(ed, static_cast<double>(cx[l]), sx);
-                    sy = fma(ed, static_cast<double>(cy[l]), sy);
-                    sz = fma(ed, static_cast<double>(cz[l]), sz);
-                }
-            } else {
-                // four voxels (x, y, z..z+3) of one grid row: moments of the voxel index
-                const unsigned row = fast_div(i, d_sz), z = i - row * d_sz.divisor;
-                const unsigned x = fast_div(row, d_sy), y = row - x * d_sy.divisor;
-                const double e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-                const double q = (e0 + e1) + (e2 + e3);
-                s += q;
-                sx = fma(q, static_cast<double>(x), sx);
-                sy = fma(q, static_cast<double>(y), sy);
-                sz = fma(q, static_cast<double>(z), sz) + fma(3.0, e3, fma(2.0, e2, e1));
-            }
+            add_moments<SRC>(coord_frame, i, e, d_sy, d_sz, s, sx, sy, sz);
             parked[(buf * NV4 + k) * kShareThreads + tid] = e;
         }
         // The four sums are reduced together.  Two quad exchanges hand each lane one quantity of its quad (lane & 3 =
@@ -457,28 +499,44 @@ __global__ __launch_bounds__(kShareThreads, 4) void soft_argmax_3d_resident(
         const unsigned volume = item / static_cast<unsigned>(team);
         const unsigned member = item - volume * static_cast<unsigned>(team);
         if (wave == 0) {
-            // the records were fetched during the reduction of the next share; fetch again until all are complete
+            // The records were fetched during the reduction of the next share; fetch again, a bounded number of
+            // times, until all are complete.  What is still missing then (a team-mate that is not resident: another
+            // kernel holds its slot) this wave computes itself.
             unsigned spins = 0;
             if (!prefetched) fetch_records(item);
+            unsigned long long missing;
             while (true) {
                 bool ready = true;
 #pragma unroll
                 for (int i = 0; i < kRecord; ++i) ready = ready && w[i] != 0;
-                if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
-                if (++spins > kTeamSpinLimit) {  // gave up: raise the flag and let the share come out as NaN
-                    if (lane == 0) __hip_atomic_store(&flags[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w[0] = __double_as_longlong(__builtin_nan(""));
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
+                missing = __builtin_amdgcn_ballot_w64(!ready || (help_always && static_cast<unsigned>(lane) != member));
+                if (missing == 0 || help_always || spins++ >= kTeamPolls) break;
+                __builtin_amdgcn_s_sleep(32);
                 fetch_records(item);
             }
             const bool counts = lane < team;  // the lanes beyond the team re-read its last record
-            const double rm = counts ? __longlong_as_double(w[0]) : -INFINITY;
-            const double rs = counts ? __longlong_as_double(w[1]) : 0.0;
-            const double rx = counts ? __longlong_as_double(w[2]) : 0.0;
-            const double ry = counts ? __longlong_as_double(w[3]) : 0.0;
-            const double rz = counts ? __longlong_as_double(w[4]) : 0.0;
+            double rm = counts ? __longlong_as_double(w[0]) : -INFINITY;
+            double rs = counts ? __longlong_as_double(w[1]) : 0.0;
+            double rx = counts ? __longlong_as_double(w[2]) : 0.0;
+            double ry = counts ? __longlong_as_double(w[3]) : 0.0;
+            double rz = counts ? __longlong_as_double(w[4]) : 0.0;
+            if (team < 64) missing &= (1ull << team) - 1ull;
+            while (missing != 0) {  // wave-uniform
+                const int i = __builtin_ctzll(missing);
+                missing &= missing - 1ull;
+                double h[kRecord];
+                const size_t b = volume / static_cast<unsigned>(J);
+                share_record_by_one_wave<SRC>(vol + static_cast<size_t>(volume) * n_vox,
+                                              SRC == 0 ? coord.volume + b * n_vox * 3 : nullptr,
+                                              static_cast<unsigned>(i) * share_vox, share_vox, mult, d_sy, d_sz, h);
+                if (lane == i) {
+                    rm = h[0];
+                    rs = h[1];
+                    rx = h[2];
+                    ry = h[3];
+                    rz = h[4];
+                }
+            }
             const double M = static_cast<double>(wave_max(static_cast<float>(rm)));  // the maxima are float32 values
             const double wgt = exp(rm - M);  // a share of -inf, and a lane beyond the team, has weight 0
             const double S = wave_sum(rs * wgt);
@@ -653,11 +711,11 @@ int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool inde
         const int64_t n_shares = n_vol_total * team;
         int64_t grid_size = resident / (team > 0 ? team : 1) * team;  // whole teams only
         if (grid_size > n_shares) grid_size = n_shares;
-        // workspace: 256 bytes of flags, then one record per share; all of it zero when the kernel starts
-        const size_t exchange_bytes = kFlagBytes + static_cast<size_t>(n_shares) * kRecord * sizeof(double);
+        // workspace: one record per share, all zero when the kernel starts
+        const size_t exchange_bytes = static_cast<size_t>(n_shares) * kRecord * sizeof(double);
         if (nv4 != 0 && grid_size >= team && n_shares < (1LL << 31) && exchange_bytes <= workspace_bytes) {
-            unsigned* flags = static_cast<unsigned*>(workspace);
-            double* records = reinterpret_cast<double*>(static_cast<unsigned char*>(workspace) + kFlagBytes);
+            double* records = static_cast<double*>(workspace);
+            const int help_always = (kernel_selection() & MVX_SELECT_SOFT_ARGMAX_HELP_ALWAYS) ? 1 : 0;
             const hipError_t e = hipMemsetAsync(workspace, 0, exchange_bytes, st);
             MVX_REQUIRE(e == hipSuccess, MVX_ERR_HIP, "mvx_soft_argmax_3d: clearing the team records failed: %s",
                         hipGetErrorString(e));
@@ -665,7 +723,7 @@ int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool inde
             const FastDiv d_sy = fast_divisor(static_cast<unsigned>(sy)), d_sz = fast_divisor(static_cast<unsigned>(sz));
 #define MVX_LAUNCH_RESIDENT_SRC(NV4, SRC)                                                                            \
     hipLaunchKernelGGL((soft_argmax_3d_resident<NV4, SRC>), grid, block, resident_lds_bytes(NV4), st, volumes, coord, n_volumes, \
-                       static_cast<unsigned>(n_vox), g, d_sy, d_sz, team, static_cast<unsigned>(n_shares), multiplier, flags,    \
+                       static_cast<unsigned>(n_vox), g, d_sy, d_sz, team, static_cast<unsigned>(n_shares), multiplier, help_always, \
                        records, out, volumes_out)
 #define MVX_LAUNCH_RESIDENT(NV4)                               \
     if (source == 0) MVX_LAUNCH_RESIDENT_SRC(NV4, 0);          \
