@@ -469,6 +469,9 @@ def run_sharded(args, dev, rank, world, total=65536, alg_block=4096, vol_block=6
             "achieved": b3 / (t_unp.mean_ms() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "algorithmic_bytes_per_launch": b3, "avg_launch_ms": t_unp.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    # the 64-frame block launch is the volumetric workload's launch: same kernel, shape, layout and coordinate source
+    roof["traffic"], roof["traffic_source"] = measured_traffic(
+        "unproject", {"frames": vol_block, "views": 4, "method": "softmax", "maps": "channel-last", "coordinates": "grid parameters"})
     extra = {"frames_this_rank": n_local, "algebraic_leg_ms": t_leg_a.mean_ms(), "volumetric_leg_ms": t_leg_v.mean_ms(),
              "soft_argmax_2d_GBps": b1 / (t_alg.mean_ms() * 1e-3) / 1e9,
              "soft_argmax_3d_GBps": b4 / (t_k4.mean_ms() * 1e-3) / 1e9,
