@@ -37,7 +37,7 @@ namespace mvx {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kChunkFrames = 8;  // frames per channel-last copy + sampling round (one per XCD)
+constexpr int kChunkFrames = 32;  // frames per channel-last copy + sampling round
 
 struct Tap {
     float w00, w01, w10, w11;  // weights of (yb, xb), (yb, xb+1), (yb+1, xb), (yb+1, xb+1)
