@@ -634,6 +634,53 @@ def test_soft_argmax_3d_one_read_kernel_against_three_passes(size, frames, joint
         assert torch.equal(again[0][keep], c2[keep]) and torch.equal(again[1][keep], p2[keep])
 
 
+@pytest.mark.parametrize("shape,swap", [((16, 32, 64), False), ((8, 64, 64), True), ((24, 16, 32), False)])
+def test_soft_argmax_3d_grid_parameters_on_grids_that_are_not_cubes(shape, swap, kernel_selection):
+    """Rotated grids with three different side lengths and steps (the index arithmetic of the kernels has no
+    power-of-two or cube assumption): the grid-parameter call against the oracle on the materialised volume, for the
+    one-read kernel and the three passes; the per-voxel evaluation bit-identical to the tensor-fed call."""
+    lib = _cabi.load()
+    rng = np.random.default_rng(5)
+    frames, joints = 3, 4
+    s0, s1, s2 = shape
+    center = torch.tensor(rng.uniform(-500, 500, (frames, 3)), dtype=torch.float32, device=dev())
+    pos = (center - torch.tensor([900.0, 1100.0, 1250.0], device=dev())).contiguous()
+    th = rng.uniform(0, 2 * np.pi, frames)
+    rot = torch.tensor(np.stack([[[np.cos(t), -np.sin(t), 0], [np.sin(t), np.cos(t), 0], [0, 0, 1]] for t in th]),
+                       dtype=torch.float32, device=dev()).reshape(frames, 9).contiguous()
+    step = (1800.0 / (s0 - 1), 2200.0 / (s1 - 1), 2500.0 / (s2 - 1))
+    step = tuple(float(np.float32(x)) for x in step)
+    coord = torch.empty((frames, s0, s1, s2, 3), dtype=torch.float32, device=dev())
+    rc = lib.mvx_build_coord_volumes(_cabi.ptr(pos), _cabi.ptr(center), _cabi.ptr(rot), frames, s0, s1, s2, step[0], step[1],
+                                     step[2], int(swap), _cabi.ptr(coord), _cabi.stream(dev()))
+    assert rc == 0, lib.mvx_last_error()
+    op.attach_grid(coord, op.VoxelGrid(pos, center, rot, step, swap, shape))
+    plain = coord.clone()
+    vols = torch.tensor(rng.normal(0, 2.0, (frames, joints, s0, s1, s2)), dtype=torch.float32, device=dev())
+    oc, ov = orc.integrate_tensor_3d_with_coordinates(vols.cpu().numpy(), plain.cpu().numpy(), True)
+    for mask in (0, _cabi.SELECT_NO_SOFT_ARGMAX_RESIDENT):
+        kernel_selection(mask)
+        c, v = op.integrate_tensor_3d_with_coordinates(vols, coord, True)
+        assert np.abs(c.cpu().numpy() - oc).max() <= MM_TOL, mask
+        np.testing.assert_allclose(v.cpu().numpy(), ov, rtol=2e-5, atol=1e-30)
+        c_only = op.integrate_tensor_3d_with_coordinates(vols, coord, True, return_volumes=False)[0]
+        assert torch.equal(c_only, op.integrate_tensor_3d_with_coordinates(vols, plain, True, return_volumes=False)[0])
+    # the same grids through the unprojection (brick and tile kernels): bit-identical to the tensor-fed call, and the
+    # oracle's values on a voxel subset
+    case = synth.volumetric_case(83, frames, 4, n_joints=2, volume_size=8)
+    feats, proj, vconf = (to_dev(case[k]) for k in ("features", "proj", "vol_confidences"))
+    sub = np.arange(3, s0 * s1 * s2, 97)
+    for mask in (0, _cabi.SELECT_NO_UNPROJECT_BRICKS):
+        kernel_selection(mask)
+        for method in ("softmax", "sum"):
+            out = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+            assert torch.equal(out, op.unproject_heatmaps(feats, proj, plain, method, vconf)), (mask, method)
+            ref = orc.unproject_heatmaps(case["features"], case["proj"], plain.cpu().numpy(), method,
+                                         case["vol_confidences"], voxel_subset=sub)
+            got = out.reshape(frames, 32, -1)[:, :, sub].cpu().numpy()
+            assert np.abs(got - ref).max() <= UNPROJ_TOL, (mask, method)
+
+
 def test_soft_argmax_3d_one_read_kernel_on_two_streams_at_once():
     """Two launches of the one-read kernel that overlap on one GPU: neither has the device to itself, so team-mates
     of a share may not be resident when their record is wanted.  Both finish and give what each gives alone."""
