@@ -41,7 +41,7 @@ def test_argument_validation_without_a_gpu():
     assert lib.mvx_unproject(None, None, None, None, 1, 4, 32, 96, 96, 4, 4, 4, 9, None, None, 0, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
     assert lib.mvx_unproject(None, None, None, None, 1, 4, 32, 1, 96, 4, 4, 4, 0, None, None, 0, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
     assert lib.mvx_unproject(None, None, None, None, 0, 4, 32, 96, 96, 4, 4, 4, 0, None, None, 0, None) == _cabi.MVX_OK
-    assert lib.mvx_unproject_workspace_bytes(64, 4, 32, 96, 96) == 8 * 4 * 96 * 96 * 32 * 4
+    assert lib.mvx_unproject_workspace_bytes(64, 4, 32, 96, 96) == 32 * 4 * 96 * 96 * 32 * 4  # rounds of 32 frames
     assert lib.mvx_unproject_workspace_bytes(2, 3, 5, 20, 28) == 2 * 3 * 20 * 28 * 8 * 4
     assert lib.mvx_soft_argmax_3d_workspace_bytes(2, 17, 64, 64, 64) == 2 * 17 * (1024 * 40 + 8)
     assert lib.mvx_soft_argmax_3d(None, None, 1, 17, 0, 64, 64, 1.0, 1, None, None, None, 0, None) == _cabi.MVX_ERR_INVALID_ARGUMENT
