@@ -12,6 +12,7 @@ import socket
 import subprocess
 import sys
 import threading
+import time
 
 
 def in_launched_rank(environ=None):
@@ -67,7 +68,6 @@ def spawn_ranks(world_size, command, timeout=None, env=None, stdout=None, stderr
         t.start()
 
     status = 0
-    import time
     deadline = None if timeout is None else time.monotonic() + timeout
     pending = set(range(world_size))
     while pending:
