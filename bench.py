@@ -187,7 +187,7 @@ def run_algebraic(args, dev, rank, world, n_views=4, frames=4096, writeback=True
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"], roof["traffic_source"] = measured_traffic(
-        "soft_argmax_2d_reg<9>", {"frames": frames, "views": v, "joints": j, "heatmap_writeback": writeback})
+        "soft_argmax_2d_reg<9>", {"maps": frames * v * j, "map": [h, w], "heatmap_writeback": writeback})  # the launch sees maps only
     extra = {"dlt_kernel_ms": k2.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err)}
     cfg = {"workload": "algebraic: soft-argmax 2D + confidence-weighted DLT, %d frames/GPU x %d views x 17 joints, 96x96 heatmaps"
                        % (frames, v), "frames_per_gpu": frames, "views": v, "joints": j, "heatmap_writeback": writeback,
@@ -552,7 +552,7 @@ def run_ransac(args, dev, rank, world, frames=4096):
             "avg_launch_ms": ka.mean_ms()}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"], roof["traffic_source"] = measured_traffic(
-        "heatmap_argmax<9>", {"frames": frames, "views": v, "joints": j, "heatmap_writeback": False})
+        "heatmap_argmax<9>", {"maps": frames * v * j, "map": [h, w], "heatmap_writeback": False})
     extra = {"ransac_kernel_and_casts_ms": kr.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err),
              "mean_inlier_views": float(torch.bitwise_and(masks.view(-1, 1) >> torch.arange(4, device=dev), 1).sum(1).float().mean())}
     cfg = {"workload": "ransac: heatmap arg-max + RANSAC (all 6 view pairs) + inlier DLT + Huber refinement, "
