@@ -525,20 +525,26 @@ __device__ unsigned long long brick_phase[8];  // summed s_memtime deltas of wav
 #define MVX_STAMP(i)
 #endif
 
+
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef __attribute__((address_space(1))) const unsigned char global_byte;
 
-// The four taps of channel quad q read from a staged patch.  `base` = byte offset of pixel (rx, ry) in the patch,
-// k0 / k1 = (row & 7) << 4 of the tap rows ry and ry + 1.
-__device__ __forceinline__ Taps4 patch_taps(const unsigned char* __restrict__ patch, unsigned base, unsigned k0,
-                                            unsigned k1, int q) {
-    const unsigned char* p0 = patch + (base + (k0 ^ (static_cast<unsigned>(q) << 4)));
-    const unsigned char* p1 = patch + (base + (k1 ^ (static_cast<unsigned>(q) << 4)));
+// The four taps of channel quad q read from a staged patch.  a0 / a1 = LDS address of the pixel (rx, ry) /
+// (rx, ry + 1) of the patch plus the swizzle (row & 7) << 4 of its row.  A pixel starts on a multiple of 128 bytes
+// (the dynamic LDS block is declared 128-byte aligned), so the swizzled position of quad q is one XOR away:
+// (pixel + (s << 4)) ^ (q << 4) = pixel + ((s ^ q) << 4), and that XOR is all the address arithmetic per row of taps.
+__device__ __forceinline__ Taps4 patch_taps(unsigned a0, unsigned a1, int q) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4 lds_v4;
+    const lds_byte* p0 = (const lds_byte*)(static_cast<uintptr_t>(a0 ^ (static_cast<unsigned>(q) << 4)));
+    const lds_byte* p1 = (const lds_byte*)(static_cast<uintptr_t>(a1 ^ (static_cast<unsigned>(q) << 4)));
+    const v4 r00 = *(lds_v4*)(p0), r01 = *(lds_v4*)(p0 + kPixelBytes);
+    const v4 r10 = *(lds_v4*)(p1), r11 = *(lds_v4*)(p1 + kPixelBytes);
     Taps4 t;
-    t.f00 = *reinterpret_cast<const float4*>(p0);
-    t.f01 = *reinterpret_cast<const float4*>(p0 + kPixelBytes);
-    t.f10 = *reinterpret_cast<const float4*>(p1 + kPatchW * kPixelBytes);
-    t.f11 = *reinterpret_cast<const float4*>(p1 + kPatchW * kPixelBytes + kPixelBytes);
+    t.f00 = make_float4(r00.x, r00.y, r00.z, r00.w);
+    t.f01 = make_float4(r01.x, r01.y, r01.z, r01.w);
+    t.f10 = make_float4(r10.x, r10.y, r10.z, r10.w);
+    t.f11 = make_float4(r11.x, r11.y, r11.z, r11.w);
     return t;
 }
 
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
                                                                        FastDiv nbz, FastDiv nby, double sx, double sy,
                                                                        float* __restrict__ vol) {
     constexpr int C = 32;
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(128) unsigned char smem[];
     BrickShared* sh = reinterpret_cast<BrickShared*>(smem + 2 * kPatchBytes);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
     float4 wt[4];
     int txb[4], tyb[4];
     int ox[4], oy[4], rows[4];
-    unsigned base[4], k0[4], k1[4];
+    unsigned a0[4], a1[4];  // LDS addresses of the taps' two rows (see patch_taps)
     bool fits = true, inside = true;
     const bool corner = (lx == 0 || lx == kBrick - 1) && (ly == 0 || ly == kBrick - 1) && (lz == 0 || lz == kBrick - 1);
     const int corner_id = ((lx & 4) | (ly & 2) | (lz & 1));  // for lx, ly, lz in {0, 7}
@@ -680,9 +686,10 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
             // voxels whose weights are all zero read the patch origin (always staged) instead of wherever the clamp went
             const int rx = any ? txb[v] - ox[v] : 0, ry = any ? tyb[v] - oy[v] : 0;
             inside = inside && rx >= 0 && rx + 1 < kPatchW && ry >= 0 && ry + 1 < rows[v];
-            base[v] = static_cast<unsigned>(ry * kPatchW + rx) * kPixelBytes;
-            k0[v] = static_cast<unsigned>(ry & 7) << 4;
-            k1[v] = static_cast<unsigned>((ry + 1) & 7) << 4;
+            const unsigned pixel = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_byte*)(smem))) + vv * kPatchBytes +
+                                   static_cast<unsigned>(ry * kPatchW + rx) * kPixelBytes;
+            a0[v] = pixel + (static_cast<unsigned>(ry & 7) << 4);
+            a1[v] = pixel + kPatchW * kPixelBytes + (static_cast<unsigned>((ry + 1) & 7) << 4);
         }
     };
     // starts the copies of the two patches of a pass: rows of 16 pixels, half a row per wave-instruction
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
 #pragma unroll
             for (int vv = 0; vv < 2; ++vv) {
                 const int v = pass * 2 + vv;
-                const Taps4 f = patch_taps(smem + vv * kPatchBytes, base[v], k0[v], k1[v], q);
+                const Taps4 f = patch_taps(a0[v], a1[v], q);
                 interpolate_x2(f, wt[v], val[vv][0], val[vv][1]);
             }
             float2v cc[4][2] = {};
