@@ -788,8 +788,8 @@ def main():
         others = {}
         todo = [("sharded_65536_frames", "sharded", with_steps(args, 2, 1))]
         if world == 1:
-            todo = [("volumetric_64_frames", "volumetric", with_steps(args, 10, 2)),
-                    ("stream16", "stream16", with_steps(args, 10, 2))] + todo
+            todo = [("volumetric_64_frames", "volumetric", with_steps(args, 20, 3)),
+                    ("stream16", "stream16", with_steps(args, 20, 3))] + todo
         for key, name, sub in todo:
             torch.cuda.empty_cache()
             rec = run_workload(name, sub, dev, rank, world)
