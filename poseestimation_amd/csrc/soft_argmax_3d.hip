@@ -851,8 +851,8 @@ extern "C" int mvx_soft_argmax_3d_static(const float* volumes, const float* coor
     void* ws = nullptr;
     const int rc = static_scratch(&ws);
     if (rc != MVX_OK) return rc;
-    // every record and pair that the later passes read is rewritten by the earlier pass of the same call, so the
-    // contents a previous call left behind need no clearing
+    // What a previous call left behind needs no clearing here: the three passes rewrite every record and pair before
+    // a later pass reads it, and the one-read kernel's records are cleared by the hipMemsetAsync ahead of it.
     CoordSource src{};
     src.volume = coords_volume;
     return soft_argmax_3d_any(volumes, src, coords_volume == nullptr, n_frames, n_volumes, sx, sy, sz, multiplier,
