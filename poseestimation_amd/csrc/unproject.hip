@@ -320,6 +320,38 @@ __global__ __launch_bounds__(kThreads) void to_channel_last(const float* __restr
     }
 }
 
+// The same for C % 32 == 0 and HW % 64 == 0 (the model's 32 x 96 x 96 maps) with 16-byte accesses on both sides: a
+// lane reads four consecutive pixels of one channel and writes four consecutive channels of one pixel, so a wave
+// instruction reads 4 runs of 256 bytes and writes 2 KB in one piece.
+__global__ __launch_bounds__(kThreads) void to_channel_last_x4(const float* __restrict__ src, int C, int HW, int p_tiles,
+                                                                int c_tiles, float* __restrict__ dst) {
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    unsigned id = blockIdx.x;
+    const int pt = id % p_tiles;
+    id /= p_tiles;
+    const int ct = id % c_tiles;
+    const size_t n = id / c_tiles;
+    const int p0 = pt * 64, c0 = ct * 32;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (tid >> 4) + 16 * i, px = (tid & 15) * 4;  // 16 lanes x 16 bytes per channel row
+        const v4 r = __builtin_nontemporal_load(reinterpret_cast<const v4*>(src + (n * C + c0 + c) * HW + p0 + px));
+        tile[c][px + 0] = r.x;
+        tile[c][px + 1] = r.y;
+        tile[c][px + 2] = r.z;
+        tile[c][px + 3] = r.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = (tid >> 3) + 32 * i, c = (tid & 7) * 4;  // 8 lanes x 16 bytes per pixel
+        const v4 r = {tile[c + 0][px], tile[c + 1][px], tile[c + 2][px], tile[c + 3][px]};
+        *reinterpret_cast<v4*>(dst + (n * HW + p0 + px) * C + c0 + c) = r;
+    }
+}
+
 // One lane per (voxel, channel quad).  feat_cl: channel-last maps of the frames this launch covers.
 template <int AGG>
 __global__ __launch_bounds__(kThreads) void unproject_generic(const float* __restrict__ feat_cl,
@@ -983,8 +1015,13 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
         if (!channels_last) {
             const int64_t t_blocks = nf * V * static_cast<int64_t>(p_tiles) * c_tiles;
             MVX_REQUIRE(t_blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: feature maps too large", name);
-            hipLaunchKernelGGL(to_channel_last, dim3(static_cast<unsigned>(t_blocks)), dim3(kThreads), 0, st,
-                               features + f0 * V * C * HW, C, Cp, HW, p_tiles, c_tiles, static_cast<float*>(workspace));
+            if (C % 32 == 0 && HW % 64 == 0 && aligned16(features) && aligned16(workspace))
+                hipLaunchKernelGGL(to_channel_last_x4, dim3(static_cast<unsigned>(t_blocks)), dim3(kThreads), 0, st,
+                                   features + f0 * V * C * HW, C, static_cast<int>(HW), p_tiles, c_tiles,
+                                   static_cast<float*>(workspace));
+            else
+                hipLaunchKernelGGL(to_channel_last, dim3(static_cast<unsigned>(t_blocks)), dim3(kThreads), 0, st,
+                                   features + f0 * V * C * HW, C, Cp, HW, p_tiles, c_tiles, static_cast<float*>(workspace));
             MVX_CHECK_LAUNCH("mvx_unproject (channel-last copy)");
             feat_cl = static_cast<const float*>(workspace);
         }
