@@ -14,9 +14,11 @@ def pytest_configure(config):
 
 
 def _has_gpu():
+    """Counts devices without initialising the HIP runtime in this process (torch.cuda.is_available() would): the
+    first GPU test starts fresh rank processes and must do so before this process has touched the GPU."""
     try:
         import torch
-        return torch.cuda.is_available()
+        return torch.cuda.device_count() > 0
     except Exception:
         return False
 
