@@ -46,7 +46,9 @@ const char* mvx_last_error(void);
 /*
  * Testing aid with no counterpart in the reference: several entry points choose between kernels that compute the
  * same result (by shape and alignment).  A bit set here (process-wide, default 0) takes one kernel out of the
- * choice, so that tests and A/B timings can run the same inputs through the others.
+ * choice, so that tests and A/B timings can run the same inputs through the others.  The mask is one plain
+ * process-wide variable read by every launch: it is NOT thread-safe and not meant for production callers (set it
+ * while no other thread is inside the library).
  */
 #define MVX_SELECT_NO_UNPROJECT_BRICKS 1u /* mvx_unproject*: 8x8x8-voxel brick kernel (4 views x 32 channels) off */
 #define MVX_SELECT_NO_DLT_ROWS 2u         /* DLT entry points: 16-lanes-per-point kernel for small batches off */
@@ -168,7 +170,10 @@ int mvx_unproject_grid(const float* features, int channels_last, const float* pr
  * volumes        [n_frames][n_volumes][sx][sy][sz]
  * coords_volume  [n_frames][sx][sy][sz][3] or NULL
  * out            [n_frames][n_volumes][3]
- * volumes_out    [n_frames][n_volumes][sx][sy][sz] or NULL to skip the write
+ * volumes_out    [n_frames][n_volumes][sx][sy][sz] or NULL to skip the write.  Either the same pointer as `volumes`
+ *                (in place: served by the three-pass kernels) or a buffer that does not overlap `volumes` at all;
+ *                a partial overlap is refused with MVX_ERR_INVALID_ARGUMENT.  The same holds for
+ *                mvx_soft_argmax_3d_grid and mvx_soft_argmax_3d_static.
  * workspace      mvx_soft_argmax_3d_workspace_bytes() bytes of device memory, 256-byte aligned
  */
 size_t mvx_soft_argmax_3d_workspace_bytes(int64_t n_frames, int n_volumes, int sx, int sy, int sz);
@@ -201,6 +206,8 @@ int mvx_soft_argmax_3d_grid(const float* volumes, const float* position, const f
  * mvx_soft_argmax_3d_workspace_bytes() exceed that size are rejected with MVX_ERR_WORKSPACE (17 volumes of
  * 64^3: up to 12 frames per call).  All calls on one GPU share the array: calls that overlap in time on one
  * GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not.
+ * The first call on a device looks up the array's address and the kernel's occupancy (which may load code objects):
+ * make one call per device outside any stream capture before capturing it into a graph.
  */
 #define MVX_SOFT_ARGMAX_3D_STATIC_BYTES (8u << 20)
 int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, int64_t n_frames, int n_volumes,

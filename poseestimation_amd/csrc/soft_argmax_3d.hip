@@ -390,7 +390,7 @@ __device__ __noinline__ void share_record_by_one_wave(const float* __restrict__ 
 }
 
 // records[volume][member] = (max, S, Sx, Sy, Sz) of the member's share,
-// sums relative to its own max; all zero bits at launch (hipMemsetAsync ahead of it), never zero once published.
+// sums relative to its own max; all zero bits at launch (a clearing kernel ahead of it), never zero once published.
 // Dynamic LDS: two buffers of 512 x NV4 float4.
 template <int NV4, int SRC>
 __global__ __launch_bounds__(kShareThreads, 4) void soft_argmax_3d_resident(
@@ -630,6 +630,11 @@ constexpr size_t resident_lds_bytes(int nv4) { return static_cast<size_t>(2) * n
 
 // Workgroups of soft_argmax_3d_resident<NV4, SRC> that the current device holds at once (cached per device):
 // compute units x workgroups per compute unit as the runtime reports them, the latter capped at two.
+__global__ void clear_records(unsigned long long* __restrict__ words, size_t n) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) words[i] = 0ull;
+}
+
 int resident_workgroups(int nv4, int source) {
     static std::mutex mutex;
     static int cached[64][3][3];  // [device][log2 nv4][source], 0 = not asked yet
@@ -679,6 +684,16 @@ int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool inde
                 "mvx_soft_argmax_3d: workspace must be 8-byte aligned");
     const int64_t n_vox = static_cast<int64_t>(sx) * sy * sz;
     const Grid3 g{sx, sy, sz};
+    // In place (volumes_out == volumes) is served by the three passes, whose last pass rewrites every element from
+    // its own value; the one-read kernel may re-read a team-mate's share from `volumes` after that share's owner has
+    // written its output.  Any other overlap of the two ranges is refused.
+    const bool in_place = volumes_out == volumes;
+    if (volumes_out != nullptr && !in_place) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(volumes), b = reinterpret_cast<uintptr_t>(volumes_out);
+        const uintptr_t bytes = static_cast<uintptr_t>(n_frames) * n_volumes * n_vox * sizeof(float);
+        MVX_REQUIRE(a + bytes <= b || b + bytes <= a, MVX_ERR_INVALID_ARGUMENT,
+                    "mvx_soft_argmax_3d: volumes_out overlaps volumes (pass the same pointer for in-place use, or disjoint buffers)");
+    }
     const bool vec = (n_vox % 4 == 0) && aligned16(volumes) && (coords_volume == nullptr || aligned16(coords_volume)) &&
                      (volumes_out == nullptr || aligned16(volumes_out));
     const int nv = pick_nv(n_frames, n_vox);
@@ -693,7 +708,7 @@ int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool inde
     double* partial = static_cast<double*>(workspace);
 
     // softmax with the normalised volumes wanted: one kernel, one read of each volume, resident workgroups
-    if (softmax && volumes_out != nullptr && vec && sz % 4 == 0 &&
+    if (softmax && volumes_out != nullptr && !in_place && vec && sz % 4 == 0 &&
         !(kernel_selection() & MVX_SELECT_NO_SOFT_ARGMAX_RESIDENT)) {
         // a share is NV4 float4 per lane of 512 threads: the largest NV4 of 4, 2, 1 that cuts the volume into 1 to 64
         const int64_t lane_span = static_cast<int64_t>(kShareThreads) * 4;
@@ -716,9 +731,12 @@ int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool inde
         if (nv4 != 0 && grid_size >= team && n_shares < (1LL << 31) && exchange_bytes <= workspace_bytes) {
             double* records = static_cast<double*>(workspace);
             const int help_always = (kernel_selection() & MVX_SELECT_SOFT_ARGMAX_HELP_ALWAYS) ? 1 : 0;
-            const hipError_t e = hipMemsetAsync(workspace, 0, exchange_bytes, st);
-            MVX_REQUIRE(e == hipSuccess, MVX_ERR_HIP, "mvx_soft_argmax_3d: clearing the team records failed: %s",
-                        hipGetErrorString(e));
+            // cleared by a kernel of our own rather than hipMemsetAsync: captured into a HIP graph, the memset node
+            // took effect on the first replay only (ROCm 7.0), a kernel node replays like any other
+            const size_t n_words = exchange_bytes / sizeof(unsigned long long);
+            hipLaunchKernelGGL(clear_records, dim3(static_cast<unsigned>((n_words + kThreads - 1) / kThreads)), dim3(kThreads),
+                               0, st, static_cast<unsigned long long*>(workspace), n_words);
+            MVX_CHECK_LAUNCH("mvx_soft_argmax_3d (clearing the team records)");
             const dim3 grid(static_cast<unsigned>(grid_size)), block(kShareThreads);
             const FastDiv d_sy = fast_divisor(static_cast<unsigned>(sy)), d_sz = fast_divisor(static_cast<unsigned>(sz));
 #define MVX_LAUNCH_RESIDENT_SRC(NV4, SRC)                                                                            \
@@ -852,7 +870,7 @@ extern "C" int mvx_soft_argmax_3d_static(const float* volumes, const float* coor
     const int rc = static_scratch(&ws);
     if (rc != MVX_OK) return rc;
     // What a previous call left behind needs no clearing here: the three passes rewrite every record and pair before
-    // a later pass reads it, and the one-read kernel's records are cleared by the hipMemsetAsync ahead of it.
+    // a later pass reads it, and the one-read kernel's records are cleared by the kernel launched ahead of it.
     CoordSource src{};
     src.volume = coords_volume;
     return soft_argmax_3d_any(volumes, src, coords_volume == nullptr, n_frames, n_volumes, sx, sy, sz, multiplier,

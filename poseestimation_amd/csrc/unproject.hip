@@ -1,32 +1,34 @@
 // Unprojection of per-view feature maps into a voxel grid with view aggregation.
 //
-// Step 1 copies the feature maps of a few frames from [view][channel][h][w] to channel-last
-// [view][h][w][channel] (channels padded to a multiple of 4), so that the C channels of one bilinear tap are
-// one contiguous C*4-byte run (a full 128-byte line for C = 32).  The copy of a chunk of frames is consumed
-// straight away by step 2 and is small enough to stay in L2 / Infinity Cache.
+// Maps arrive either channel-last already ([view][h][w][channel]) or as [view][channel][h][w]; the latter are first
+// copied to channel-last (channels padded to a multiple of 4) in rounds of kChunkFrames = 32 frames, so that the C
+// channels of one bilinear tap are one contiguous C*4-byte run (a full 128-byte line for C = 32).  Each round's
+// copy is sampled straight away by the kernels below.
 //
-// Step 2, tile kernel (C = 32): a workgroup owns 128 consecutive voxels of one frame.
+// Brick kernel (unproject_brick32; the default for 4 views of 32 channels and grid sides that are multiples of 8):
+// a workgroup owns 8 x 8 x 8 voxels, stages the <= 16 x 16-pixel patches of the maps that its taps fall into in LDS
+// (global -> LDS copies, two views at a time) and reads the taps from there.  See the comment above the kernel.
+//
+// Tile kernel (unproject_tile32: C = 32, up to 16 views, any grid whose voxel count is a multiple of 128): a
+// workgroup owns 128 consecutive voxels of one frame.
 //   phase A  one thread per voxel projects it into every view and leaves the four bilinear weights (zero for
 //            taps outside the map and for voxels behind the camera) and the tap address in LDS;
 //   phase B  8 lanes per voxel, 4 channels per lane: four 16-byte loads per view fetch the 2x2 taps (each
 //            wave-instruction consumes whole 128-byte lines), the view aggregation runs in registers
-//            (sum / confidence-weighted / max / online softmax over views), results go to an LDS tile
+//            (sum / confidence-weighted / max / softmax over views), results go to an LDS tile
 //            [channel][voxel] (XOR-swizzled so both sides are conflict-free);
 //   phase C  the tile is stored with 16 bytes per lane: 512 contiguous bytes per channel.
-// The per-view volumes of the reference (V x C x N floats per frame) are never materialised.
-// Workgroup ids are remapped so that each XCD works through consecutive tiles of the same frame and its L2
-// holds just that frame's feature maps.
+// It is bound by the vector-memory return path (512 B of taps per voxel and view through the L1 whether or not the
+// lines hit), which is what the brick kernel's LDS patches avoid.
 //
-// Step 2, generic kernel (any C, V, grid): one lane per (voxel, 4 channels), no LDS, direct stores.
+// Generic kernel (any C, V, grid): one lane per (voxel, 4 channels), no LDS, direct stores.
 //
-// Measured on MI355X (8 frames per launch, V = 4): the tile kernel is bound by the vector-memory return path
-// (64 B/clk per CU; 512 B of taps per voxel and view whether or not the lines hit in L1), at about 21 us per
-// frame against a 6.6 us HBM floor.  A variant that fed the taps from an LDS patch staged per view and 2x2x32
-// tile was measured slower and is not kept (its stage / sample phases serialise at 2-3 workgroups per CU:
-// 3.0 ms against 1.6 ms for 64 frames); taps read from LDS with no staging cost bound what such a design
-// could reach at about 0.9-1.1 ms.
+// The per-view volumes of the reference (V x C x N floats per frame) are never materialised.  Workgroup ids are
+// remapped so that each XCD works through consecutive bricks / tiles of the same frame and its L2 holds just that
+// frame's feature maps.
 //
-// HBM traffic per frame: V*C*h*w*4 (features) + N*12 (coordinates) + C*N*4 (volume written).
+// HBM traffic per frame: V*C*h*w*4 (features) + N*12 (coordinates, unless the grid parameters are given) + C*N*4
+// (volume written).
 #include <limits.h>
 #include <stdlib.h>
 
@@ -542,6 +544,7 @@ struct BrickShared {
     double cam[4 * 12];
     int corner[4][2][8];  // floor position (x0, y0) of the 8 corner voxels per view; INT_MAX for a corner behind the camera
     int bad;              // some lane's taps lie outside the patches
+    int redo;             // the view softmax left the range in which its unshifted form is exact
 };
 
 #ifdef MVX_BRICK_STATS  // development builds only (tools/brick_stats.hip)
@@ -605,7 +608,7 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], int lane) {
     }
 }
 
-template <int AGG, bool GRID>
+template <int AGG, bool GRID, bool UNITS = true>
 __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const float* __restrict__ feat_cl,
                                                                        const float* __restrict__ proj,
                                                                        VoxelSource coord,
@@ -649,26 +652,33 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
     if (tid < 48) sh->cam[tid] = camera_entry(proj + b * 48 + (tid / 12) * 12, tid % 12, sx, sy);
-    if (tid == 64) sh->bad = 0;
+    if (tid == 64) {
+        sh->bad = 0;
+        sh->redo = 0;
+    }
     __syncthreads();
 
     // 1./2. projection, patch rectangles and per-lane check, a pair of views at a time: the patches of views 0 and 1
     // are on their way into LDS while views 2 and 3 are projected.
     double X, Y, Z;
-    if (GRID) {
-        FrameGrid fg;
-        fg.load(coord.grid, coord.first_frame + b, vy);
-        float x, y, z;
-        fg.at(bx * kBrick + lx, by * kBrick + ly, bz * kBrick + lz, x, y, z);
-        X = x;
-        Y = y;
-        Z = z;
-    } else {
-        const float* cp = coord.volume + (b * n_vox + n) * 3;
-        X = cp[0];
-        Y = cp[1];
-        Z = cp[2];
-    }
+    // world position of this lane's voxel; `lz_` is lz (passed so that a second evaluation is not merged with the first)
+    auto load_position = [&](int lz_) __attribute__((always_inline)) {
+        if (GRID) {
+            FrameGrid fg;
+            fg.load(coord.grid, coord.first_frame + b, vy);
+            float x, y, z;
+            fg.at(bx * kBrick + lx, by * kBrick + ly, bz * kBrick + lz_, x, y, z);
+            X = x;
+            Y = y;
+            Z = z;
+        } else {
+            const float* cp = coord.volume + (b * n_vox + (n - lz + lz_)) * 3;
+            X = cp[0];
+            Y = cp[1];
+            Z = cp[2];
+        }
+    };
+    load_position(lz);
     float4 wt[4];
     int txb[4], tyb[4];
     int ox[4], oy[4], rows[4];
@@ -774,11 +784,11 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
         atomicMax(&brick_stats[3], static_cast<unsigned>(max(max(rows[0], rows[1]), max(rows[2], rows[3]))));
     }
 #endif
-    if (!staged) {
-        // Direct path: taps from global memory with the tile kernel's access shape -- 8 lanes per voxel, each
-        // fetching its 16 bytes of whole 128-byte lines -- and the same arithmetic.  The weights and tap pixels
-        // change lanes through tables in the (unused) patch area; slots are ordered so that the 8 voxels of a step
-        // are consecutive along z.
+    // Direct path: taps from global memory with the tile kernel's access shape -- 8 lanes per voxel, each fetching
+    // its 16 bytes of whole 128-byte lines -- and the same arithmetic.  The weights and tap pixels change lanes
+    // through tables in the (unused) patch area; slots are ordered so that the 8 voxels of a step are consecutive
+    // along z.
+    auto direct_path = [&]() __attribute__((always_inline)) {
         float4* wts = reinterpret_cast<float4*>(smem);                                          // [4][512]
         unsigned* pix = reinterpret_cast<unsigned*>(smem + 4 * kBrickThreads * sizeof(float4));  // [4][512]
         unsigned* vox = pix + 4 * kBrickThreads;                                                // [512]
@@ -820,6 +830,124 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
             for (int k = 0; k < 4; ++k)
                 dst[static_cast<int64_t>(q * 4 + k) * n_vox] = combine_four<AGG>(
                     val[0][k], val[1][k], val[2][k], val[3][k], cc[0][k], cc[1][k], cc[2][k], cc[3][k]);
+        }
+    };
+    if (!staged) {
+        direct_path();
+        return;
+    }
+
+    if (UNITS) {
+        // 3./4. four units of one view each.  View v lives in buffer v & 1: while unit 0 (1) is sampled the patch
+        // of view 2 (3) is on its way into the buffer that unit has just left, so no wave waits for a copy that
+        // has just been issued.  The views are aggregated one at a time in registers.  sum / conf / max: the same
+        // operations in the same order as the tile kernel (bit-identical).  The view softmax
+        // sum_v x_v e^{x_v} / sum_v e^{x_v} is accumulated without subtracting the maximum over views -- two
+        // registers per channel, no second look at the values -- which is the same quotient as long as no term
+        // overflows and the largest term is not flushed.  That is checked, not assumed: every denominator must lie
+        // in [2^-80, 2^100] (a term below 2^-46 of the largest may then have been lost to underflow at most); a
+        // brick that fails the check is computed again by the direct path, which evaluates the shifted form.
+        // Results differ from the shifted form by the rounding of the exponentials only (a few float32 ulps).
+        auto stage_one = [&](int v) {
+            global_byte* img = (global_byte*)(fb + v * img_stride);
+            lds_byte* dst = (lds_byte*)(smem) + (v & 1) * kPatchBytes;
+#pragma unroll
+            for (int it = 0; it < kPatchRows / 4; ++it) {
+                const int py = it * 4 + (wave >> 1);  // wave-uniform
+                if (py < rows[v]) {
+                    const int px = ((wave & 1) << 3) + (lane >> 3);
+                    const int q = (lane & 7) ^ (py & 7);
+                    const int gx = min(ox[v] + px, W - 1), gy = oy[v] + py;
+                    const unsigned src = (static_cast<unsigned>(gy * W + gx) * C + static_cast<unsigned>(q) * 4u) * 4u;
+                    __builtin_amdgcn_global_load_lds(img + src, dst + (py * kPatchW + ((wave & 1) << 3)) * kPixelBytes,
+                                                     16, 0, 0);
+                }
+            }
+        };
+        float2v acc[C / 2];  // sum / conf / max: the aggregate; softmax: the numerator
+        float2v den[AGG == MVX_AGG_SOFTMAX ? C / 2 : 1];
+        float2v chk_d = {0.0f, 0.0f}, chk_r = {0.0f, 0.0f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (v == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every lane has read view 0
+                stage_one(2);
+            } else if (v == 2) {
+                // this wave's copies of view 2 have landed; then: everybody's have, and every lane has read view 1
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                stage_one(3);
+            } else if (v == 3) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float2v val[2];
+                const Taps4 f = patch_taps(a0[v], a1[v], q);
+                interpolate_x2(f, wt[v], val[0], val[1]);
+                float2v cc[2] = {};
+                if (AGG == MVX_AGG_CONF) {
+                    const float* cv = vconf + (b * 4 + v) * C + q * 4;
+                    cc[0] = float2v{cv[0], cv[1]};
+                    cc[1] = float2v{cv[2], cv[3]};
+                }
+                float res[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cp = q * 2 + h;  // channel pair
+                    if (AGG == MVX_AGG_SUM) {
+                        acc[cp] = v == 0 ? val[h] : acc[cp] + val[h];
+                    } else if (AGG == MVX_AGG_CONF) {
+                        acc[cp] = v == 0 ? val[h] * cc[h] : __builtin_elementwise_fma(val[h], cc[h], acc[cp]);
+                    } else if (AGG == MVX_AGG_MAX) {
+                        acc[cp] = v == 0 ? val[h] : float2v{fmaxf(acc[cp].x, val[h].x), fmaxf(acc[cp].y, val[h].y)};
+                    } else {
+                        const float2v e = {__builtin_amdgcn_exp2f(val[h].x), __builtin_amdgcn_exp2f(val[h].y)};
+                        den[cp] = v == 0 ? e : den[cp] + e;
+                        acc[cp] = v == 0 ? e * val[h] : __builtin_elementwise_fma(e, val[h], acc[cp]);
+                    }
+                    // pin the running values here: left alone, the compiler sinks the interpolation towards the next
+                    // unit and carries the raw taps (four times as many registers) instead
+                    asm volatile("" : "+v"(acc[cp]));
+                    if (AGG == MVX_AGG_SOFTMAX) asm volatile("" : "+v"(den[cp]));
+                    if (v == 3) {
+                        float2v r = acc[cp];
+                        if (AGG == MVX_AGG_SOFTMAX) {
+                            const float2v rden = {__builtin_amdgcn_rcpf(den[cp].x), __builtin_amdgcn_rcpf(den[cp].y)};
+                            chk_d = chk_d + den[cp];
+                            chk_r = chk_r + rden;
+                            r = r * rden * float2v{kLn2, kLn2};
+                        }
+                        res[h * 2] = r.x;
+                        res[h * 2 + 1] = r.y;
+                    }
+                }
+                if (v == 3) {
+                    // the four lanes of a quad hold four consecutive voxels along z: after the transpose each lane
+                    // stores one channel of all four with a single 16-byte store
+                    quad_transpose(res, lane);
+                    *reinterpret_cast<float4*>(vol + quad_off + static_cast<int64_t>(q * 4) * n_vox) =
+                        make_float4(res[0], res[1], res[2], res[3]);
+                }
+                // keep the quads in order: hoisting the reads of later quads would need hundreds of registers
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (AGG == MVX_AGG_SOFTMAX) {
+            // every denominator in [2^-80, 2^100] (a NaN fails both comparisons)
+            if (!(chk_d.x + chk_d.y <= 0x1p100f) || !(chk_r.x + chk_r.y <= 0x1p80f)) sh->redo = 1;
+            // The stores above have left this wave before anybody stores the same voxels again.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (sh->redo != 0) {
+                // weights and tap pixels once more (rather than kept in registers through the sampling above)
+                int lz_again = lz;
+                asm volatile("" : "+v"(lz_again));
+                load_position(lz_again);
+                project_pair(0);
+                project_pair(1);
+                direct_path();
+            }
         }
         return;
     }

@@ -348,9 +348,11 @@ def no_bricks():
                                         (30000.0, (32, 32, 32)), (600.0, (32, 32, 32))])
 def test_unproject_brick_kernel_equals_tile_kernel(side, shape, no_bricks):
     """The brick kernel (patches of the maps staged in LDS) and the tile kernel (taps from global memory) share
-    their arithmetic: bit-identical volumes for all aggregations.  2.5 m: the reference's cuboid; 9 m and 30 m:
-    bricks whose patches exceed 16 x 16 pixels or that straddle / miss the maps (direct path inside the brick
-    kernel); 0.6 m: many voxels per pixel."""
+    their arithmetic: bit-identical volumes for sum, conf and max.  The brick kernel accumulates the view softmax
+    without subtracting the maximum over views (checked per brick, with the shifted form as the fallback), which
+    differs from the tile kernel's shifted form by the rounding of the exponentials: a few float32 ulps.
+    2.5 m: the reference's cuboid; 9 m and 30 m: bricks whose patches exceed 16 x 16 pixels or that straddle / miss
+    the maps (direct path inside the brick kernel); 0.6 m: many voxels per pixel."""
     case = synth.volumetric_case(23, 2, 4, volume_size=64, cuboid_side=side, with_volumes=False)
     feats, proj, vconf = (to_dev(case[k]) for k in ("features", "proj", "vol_confidences"))
     coord = to_dev(np.ascontiguousarray(case["coord_volumes"][:, :shape[0], :shape[1], :shape[2]]))
@@ -359,7 +361,31 @@ def test_unproject_brick_kernel_equals_tile_kernel(side, shape, no_bricks):
         brick = op.unproject_heatmaps(feats, proj, coord, method, vconf)
         no_bricks(True)
         tile = op.unproject_heatmaps(feats, proj, coord, method, vconf)
-        assert torch.equal(brick, tile), method
+        if method == "softmax":
+            assert torch.allclose(brick, tile, rtol=2e-6, atol=2e-6), (brick - tile).abs().max().item()
+        else:
+            assert torch.equal(brick, tile), method
+    # features far outside the range in which the unshifted softmax is exact (exponents of +-600 and more): every
+    # brick fails its range check and is computed again in the shifted form, so nothing overflows or turns NaN
+    big = feats * 300.0
+    no_bricks(False)
+    brick_big = op.unproject_heatmaps(big, proj, coord, "softmax", vconf)
+    no_bricks(True)
+    tile_big = op.unproject_heatmaps(big, proj, coord, "softmax", vconf)
+    assert torch.isfinite(tile_big).all() and torch.isfinite(brick_big).all()
+    assert torch.allclose(brick_big, tile_big, rtol=2e-6, atol=6e-4), (brick_big - tile_big).abs().max().item()
+    # ... and a batch in which only a few voxels are out of range
+    some = feats.clone()
+    some[0, 1, 3, 40:56, 40:56] = 250.0
+    some[1, 2, 7, 30:50, 30:50] = -400.0
+    no_bricks(False)
+    brick_some = op.unproject_heatmaps(some, proj, coord, "softmax", vconf)
+    no_bricks(True)
+    tile_some = op.unproject_heatmaps(some, proj, coord, "softmax", vconf)
+    assert torch.isfinite(brick_some).all()
+    assert torch.allclose(brick_some, tile_some, rtol=2e-6, atol=2e-4), (brick_some - tile_some).abs().max().item()
+    no_bricks(False)
+    brick = op.unproject_heatmaps(feats, proj, coord, "softmax", vconf)
     # coordinates that are no grid at all (shuffled voxels): the corner test cannot vouch for the patches, the
     # per-lane check sends the bricks down the direct path
     no_bricks(False)
@@ -367,7 +393,7 @@ def test_unproject_brick_kernel_equals_tile_kernel(side, shape, no_bricks):
     perm = torch.randperm(flat.shape[1], generator=torch.Generator().manual_seed(1)).to(dev())
     shuffled = flat[:, perm].contiguous().view(coord.shape)
     got = op.unproject_heatmaps(feats, proj, shuffled, "softmax", vconf)
-    want = brick.view(2, 32, -1)[:, :, perm].view(brick.shape)
+    want = tile.view(2, 32, -1)[:, :, perm].view(tile.shape)   # the direct path evaluates the shifted form
     assert torch.equal(got, want)
 
 
@@ -577,7 +603,7 @@ def kernel_selection():
 @pytest.mark.parametrize("size,frames,joints", [(64, 3, 17), (64, 40, 17), (32, 5, 4), (16, 2, 3)])
 def test_soft_argmax_3d_one_read_kernel_against_three_passes(size, frames, joints, kernel_selection):
     """Softmax with the normalised volumes wanted: the one-read kernel (resident workgroups that keep shares of a
-    volume in registers and exchange their partial sums: 16 shares for 64^3, 2 for 32^3, 1 for 16^3) and the
+    volume in registers and exchange their partial sums: 32 shares for 64^3, 4 for 32^3, 1 for 16^3) and the
     three-pass path give the oracle's answer.  40 frames x 17 volumes of 64^3 are more shares than are resident at
     once, so every workgroup walks several."""
     if frames > 8:
@@ -632,6 +658,47 @@ def test_soft_argmax_3d_one_read_kernel_against_three_passes(size, frames, joint
     for _ in range(3):
         again = op.integrate_tensor_3d_with_coordinates(v2, coord)
         assert torch.equal(again[0][keep], c2[keep]) and torch.equal(again[1][keep], p2[keep])
+
+
+def test_soft_argmax_3d_in_place_and_overlapping_outputs(kernel_selection):
+    """volumes_out == volumes (in place) must give what the out-of-place call gives -- also with every workgroup of
+    the one-read kernel forced to re-read its team-mates' shares, the situation in which an in-place one-read kernel
+    would read values already overwritten -- and a volumes_out that overlaps `volumes` partially is refused."""
+    lib = _cabi.load()
+    case = synth.volumetric_case(91, 3, 2, n_joints=17, volume_size=64)
+    vols = to_dev(case["volumes"])
+    coord = to_dev(case["coord_volumes"])
+    b, j, sx, sy, sz = vols.shape
+    need = lib.mvx_soft_argmax_3d_workspace_bytes(b, j, sx, sy, sz)
+    ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev())
+
+    def call(src, dst):
+        out = torch.full((b, j, 3), float("nan"), dtype=torch.float32, device=dev())
+        rc = lib.mvx_soft_argmax_3d(_cabi.ptr(src), _cabi.ptr(coord), b, j, sx, sy, sz, 1.0, 1, _cabi.ptr(out), _cabi.ptr(dst),
+                                    _cabi.ptr(ws), ws.numel() * 8, _cabi.stream(dev()))
+        torch.cuda.synchronize()
+        return rc, out
+
+    apart = torch.empty_like(vols)
+    rc, out_apart = call(vols, apart)
+    assert rc == 0, lib.mvx_last_error()
+    for mask in (0, _cabi.SELECT_SOFT_ARGMAX_HELP_ALWAYS, _cabi.SELECT_NO_SOFT_ARGMAX_RESIDENT):
+        kernel_selection(mask)
+        buf = vols.clone()
+        rc, out_in_place = call(buf, buf)
+        assert rc == 0, lib.mvx_last_error()
+        assert torch.allclose(out_in_place, out_apart, rtol=0, atol=2e-4), mask
+        assert torch.allclose(buf, apart, rtol=2e-5, atol=0), mask
+    kernel_selection(0)
+    # one buffer holding the input and, one volume further on, the output: refused, nothing written
+    n_vox = sx * sy * sz
+    pool = torch.zeros(vols.numel() + n_vox, dtype=torch.float32, device=dev())
+    pool[: vols.numel()] = vols.view(-1)
+    before = pool.clone()
+    rc, _ = call(pool[: vols.numel()], pool[n_vox:])
+    assert rc == _cabi.MVX_ERR_INVALID_ARGUMENT
+    assert b"overlaps" in lib.mvx_last_error()
+    assert torch.equal(pool, before)
 
 
 @pytest.mark.parametrize("shape,swap", [((16, 32, 64), False), ((8, 64, 64), True), ((24, 16, 32), False)])

@@ -86,3 +86,37 @@ def test_static_scratch_entry_rejects_oversize_and_allocates_nothing():
     torch.cuda.synchronize(dev)
     free1, _ = torch.cuda.mem_get_info(dev)
     assert free1 == free0
+
+
+def test_static_scratch_entry_under_graph_capture():
+    """What the entry point is for: after one warm-up call per device (address look-up, occupancy query), the call is
+    captured into a HIP graph (the kernel that clears the team records and the one-read kernel become its nodes) and
+    three replays give the workspace entry's result bit for bit.  (With hipMemsetAsync in place of the clearing
+    kernel the memset node took effect on the first replay only, and later replays combined stale records.)"""
+    lib = _cabi.load()
+    dev = torch.device("cuda:0")
+    case = synth.volumetric_case(44, 2, 2, n_joints=17, volume_size=32)
+    vols = torch.from_numpy(case["volumes"]).to(dev)
+    coord = torch.from_numpy(case["coord_volumes"]).to(dev)
+    rc_w, out_w, vout_w = _run(lib, "workspace", vols, coord, True, 1.0, True)
+    assert rc_w == 0
+    out = torch.empty((2, 17, 3), dtype=torch.float32, device=dev)
+    vout = torch.empty_like(vols)
+    src = vols.clone()
+
+    def call():
+        return lib.mvx_soft_argmax_3d_static(_cabi.ptr(src), _cabi.ptr(coord), 2, 17, 32, 32, 32, 1.0, 1, _cabi.ptr(out),
+                                             _cabi.ptr(vout), _cabi.stream(dev))
+
+    assert call() == 0  # warm-up outside the capture
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rc = call()
+    assert rc == 0, lib.mvx_last_error()
+    for _ in range(3):
+        out.fill_(float("nan"))
+        vout.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out, out_w) and torch.equal(vout, vout_w)

@@ -1,0 +1,230 @@
+// Development tool: times variants of the brick unprojection kernel on the benchmark geometry (64 frames, 4 views,
+// 32 channels, 64^3 voxels, regular grid given by its parameters, channel-last maps) and compares their output with
+// the library call.  Inputs come from tools/brick_lab.py.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/brick_lab.hip poseestimation_amd/csrc/mvx_core.hip -o tools/brick_lab
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../poseestimation_amd/csrc/unproject.hip"
+
+// the experimental streaming (resident-workgroup) form of the brick kernel: not part of the library
+namespace mvx {
+namespace {
+#include "unproject_stream.h"
+}  // namespace
+}  // namespace mvx
+
+__global__ void fill_normalish(float* p, size_t n, unsigned seed) {
+    size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    float s = 0.0f;
+    for (int k = 0; k < 4; ++k) {
+        x ^= x >> 29;
+        x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 32;
+        s += static_cast<float>(x & 0xffffff) * (1.0f / 16777216.0f);
+    }
+    p[i] = (s - 2.0f) * 1.7320508f;  // sum of four uniforms: mean 2, variance 1/3
+}
+
+struct Case {
+    int B = 0, S = 64, H = 96, W = 96;
+    float *proj = nullptr, *pos = nullptr, *center = nullptr, *rot = nullptr, *feat = nullptr, *vol = nullptr, *ref = nullptr;
+    float step = 0.0f;
+};
+
+template <class F>
+static float time_ms(F&& launch, int reps = 15) {
+    for (int i = 0; i < 2; ++i) launch();
+    if (hipDeviceSynchronize() != hipSuccess) {
+        printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
+        exit(1);
+    }
+    std::vector<float> t;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < reps; ++i) {
+        hipEventRecord(e0, 0);
+        launch();
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        t.push_back(ms);
+    }
+    printf("    series:");
+    for (float x : t) printf(" %.3f", x);
+    printf("\n");
+    std::sort(t.begin(), t.end());
+    printf("    [min %.3f  median %.3f  max %.3f ms]\n", t.front(), t[t.size() / 2], t.back());
+    return t[t.size() / 2];
+}
+
+static void compare(const Case& c, const char* what) {
+    const size_t n = static_cast<size_t>(c.B) * 32 * c.S * c.S * c.S;
+    std::vector<float> a(n), b(n);
+    hipMemcpy(a.data(), c.vol, n * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(b.data(), c.ref, n * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    size_t differing = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double d = fabs(static_cast<double>(a[i]) - b[i]);
+        if (!(d == 0)) ++differing;
+        if (!(d <= worst)) worst = d;
+    }
+    printf("    %s vs library: %zu of %zu elements differ, max abs %.3g\n", what, differing, n, worst);
+}
+
+// the library's brick kernel launched directly, with `extra_lds` bytes of unused LDS to lower the residency
+template <int AGG, bool UNITS = true>
+static void launch_brick(const Case& c, size_t extra_lds, float* out = nullptr) {
+    using namespace mvx;
+    const int bricks = (c.S / kBrick) * (c.S / kBrick) * (c.S / kBrick);
+    VoxelSource cd{};
+    cd.grid = GridSpec{c.pos, c.center, c.rot, c.step, c.step, c.step, 0};
+    cd.has_grid = 1;
+    cd.vy = c.S;
+    cd.vz = c.S;
+    const double sx = static_cast<double>(c.W - 1) / c.H, sy = static_cast<double>(c.H - 1) / c.W;
+    hipLaunchKernelGGL((unproject_brick32<AGG, true, UNITS>), dim3(c.B * bricks), dim3(kBrickThreads),
+                       2 * kPatchBytes + sizeof(BrickShared) + extra_lds, 0, c.feat, c.proj, cd, nullptr, c.H, c.W, c.S, c.S,
+                       c.S, fast_divisor(bricks), fast_divisor(c.S / kBrick), fast_divisor(c.S / kBrick), sx, sy,
+                       out != nullptr ? out : c.vol);
+}
+
+template <int AGG>
+static void launch_stream(const Case& c, int frames) {
+    using namespace mvx;
+    const int bricks = (c.S / kBrick) * (c.S / kBrick) * (c.S / kBrick);
+    VoxelSource cd{};
+    cd.grid = GridSpec{c.pos, c.center, c.rot, c.step, c.step, c.step, 0};
+    cd.has_grid = 1;
+    cd.vy = c.S;
+    cd.vz = c.S;
+    const double sx = static_cast<double>(c.W - 1) / c.H, sy = static_cast<double>(c.H - 1) / c.W;
+    const unsigned n_items = static_cast<unsigned>(frames * bricks);
+    hipLaunchKernelGGL((unproject_brick_stream<AGG, true>), dim3(n_items < 512u ? n_items : 512u), dim3(kBrickThreads),
+                       2 * kPatchBytes + sizeof(StreamShared), 0, c.feat, c.proj, cd, nullptr, 4, c.H, c.W, c.S, c.S, c.S,
+                       fast_divisor(bricks), fast_divisor(c.S / kBrick), fast_divisor(c.S / kBrick), n_items, sx, sy, c.vol);
+}
+
+int main(int argc, char** argv) {
+    const char* path = argc > 1 ? argv[1] : "/tmp/brick_lab.bin";
+    FILE* f = fopen(path, "rb");
+    if (!f) { printf("cannot open %s\n", path); return 1; }
+    Case c;
+    if (fread(&c.B, 4, 1, f) != 1) return 1;
+    std::vector<float> proj(c.B * 48), base(c.B * 3), pos(c.B * 3), rot(c.B * 9, 0.0f);
+    if (fread(proj.data(), 4, proj.size(), f) != proj.size() || fread(base.data(), 4, base.size(), f) != base.size()) return 1;
+    fclose(f);
+    for (int b = 0; b < c.B; ++b) {
+        for (int k = 0; k < 3; ++k) pos[b * 3 + k] = base[b * 3 + k] - 1250.0f;
+        rot[b * 9 + 0] = rot[b * 9 + 4] = rot[b * 9 + 8] = 1.0f;
+    }
+    c.step = static_cast<float>(2500.0 / 63.0);
+    const size_t nfeat = static_cast<size_t>(c.B) * 4 * 32 * c.H * c.W, nvol = static_cast<size_t>(c.B) * 32 * c.S * c.S * c.S;
+    hipMalloc(&c.proj, proj.size() * 4);
+    hipMalloc(&c.pos, pos.size() * 4);
+    hipMalloc(&c.center, base.size() * 4);
+    hipMalloc(&c.rot, rot.size() * 4);
+    hipMalloc(&c.feat, nfeat * 4);
+    hipMalloc(&c.vol, nvol * 4);
+    hipMalloc(&c.ref, nvol * 4);
+    hipMemcpy(c.proj, proj.data(), proj.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(c.pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(c.center, base.data(), base.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(c.rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(fill_normalish, dim3((nfeat + 255) / 256), dim3(256), 0, 0, c.feat, nfeat, 17u);
+    hipDeviceSynchronize();
+
+    auto library = [&](int agg, float* out) {
+        const int rc = mvx_unproject_grid(c.feat, 1, c.proj, c.pos, c.center, c.rot, c.step, c.step, c.step, 0, nullptr, c.B, 4,
+                                          32, c.H, c.W, c.S, c.S, c.S, agg, out, nullptr, 0, nullptr);
+        if (rc != 0) printf("mvx_unproject_grid: %s\n", mvx_last_error());
+    };
+    if (argc > 2 && std::string(argv[2]) != "with-stream") {
+        // profiling mode: a few launches of one variant and nothing else
+        //   brick_lab <case> lib-softmax|lib-sum|one-per-cu [launches]
+        const std::string which = argv[2];
+        const int n = argc > 3 ? atoi(argv[3]) : 3;
+        for (int i = 0; i < n; ++i) {
+            if (which == "stream-softmax") launch_stream<MVX_AGG_SOFTMAX>(c, c.B);
+            else if (which == "lib-softmax") library(MVX_AGG_SOFTMAX, c.vol);
+            else if (which == "lib-sum") library(MVX_AGG_SUM, c.vol);
+            else if (which == "one-per-cu") launch_brick<MVX_AGG_SOFTMAX>(c, 20 << 10);
+            else { printf("unknown variant %s\n", which.c_str()); return 1; }
+        }
+        hipDeviceSynchronize();
+        printf("done %s x %d\n", which.c_str(), n);
+        return 0;
+    }
+#ifdef MVX_STREAM_DEBUG
+    {
+        // every global access of the streaming kernel checked and redirected; features switched on one at a time
+        using namespace mvx;
+        StreamDebug h{}, *d = nullptr;
+        hipMalloc(&d, sizeof(StreamDebug));
+        const int bricks = (c.S / kBrick) * (c.S / kBrick) * (c.S / kBrick);
+        const int frames = argc > 2 ? atoi(argv[2]) : c.B;
+        for (unsigned mask : {0u, 1u, 3u, 7u}) {
+            h = StreamDebug{};
+            h.lo[0] = (const char*)c.feat;
+            h.hi[0] = (const char*)(c.feat + nfeat);
+            h.lo[1] = (const char*)c.vol;
+            h.hi[1] = (const char*)(c.vol + nvol);
+            h.n_frames = frames;
+            h.mask = mask;
+            hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice);
+            VoxelSource cd{};
+            cd.volume = reinterpret_cast<const float*>(d);
+            cd.grid = GridSpec{c.pos, c.center, c.rot, c.step, c.step, c.step, 0};
+            cd.has_grid = 1;
+            cd.vy = c.S;
+            cd.vz = c.S;
+            const double sx = static_cast<double>(c.W - 1) / c.H, sy = static_cast<double>(c.H - 1) / c.W;
+            const unsigned n_items = static_cast<unsigned>(frames * bricks);
+            printf("mask %u: launching %u bricks on %u workgroups\n", mask, n_items, n_items < 512u ? n_items : 512u);
+            fflush(stdout);
+            hipLaunchKernelGGL((unproject_brick_stream<MVX_AGG_MAX, true>), dim3(n_items < 512u ? n_items : 512u), dim3(kBrickThreads),
+                               2 * kPatchBytes + sizeof(StreamShared), 0, c.feat, c.proj, cd, nullptr, 4, c.H, c.W, c.S, c.S, c.S,
+                               fast_divisor(bricks), fast_divisor(c.S / kBrick), fast_divisor(c.S / kBrick), n_items, sx, sy, c.vol);
+            const hipError_t e = hipDeviceSynchronize();
+            printf("mask %u: %s\n", mask, hipGetErrorString(e));
+            fflush(stdout);
+            if (e != hipSuccess) return 1;
+            hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+            const char* kinds[4] = {"feature read", "volume write", "brick decode", "direct-path table entry"};
+            for (int k = 0; k < 4; ++k)
+                printf("  %-24s outside %llu times; first: value %lld, block %llu, thread %llu, line %llu\n", kinds[k], h.count[k],
+                       (long long)h.first[k][0], h.first[k][1], h.first[k][2], h.first[k][3]);
+            fflush(stdout);
+        }
+        return 0;
+    }
+#endif
+    const bool with_stream = argc > 2 && std::string(argv[2]) == "with-stream";
+    for (int agg : {MVX_AGG_SOFTMAX, MVX_AGG_SUM, MVX_AGG_MAX}) {  // no confidences in this harness
+        printf("aggregation %d: brick kernel, two passes of two views\n", agg);
+        time_ms([&] {
+            if (agg == MVX_AGG_SOFTMAX) launch_brick<MVX_AGG_SOFTMAX, false>(c, 0, c.ref);
+            else if (agg == MVX_AGG_SUM) launch_brick<MVX_AGG_SUM, false>(c, 0, c.ref);
+            else launch_brick<MVX_AGG_MAX, false>(c, 0, c.ref);
+        });
+        printf("aggregation %d: brick kernel, four units of one view (the library's)\n", agg);
+        time_ms([&] { library(agg, c.vol); }, 40);
+        compare(c, "units");
+        if (with_stream) {
+            printf("aggregation %d: streaming brick kernel\n", agg);
+            time_ms([&] {
+                if (agg == MVX_AGG_SOFTMAX) launch_stream<MVX_AGG_SOFTMAX>(c, c.B);
+                else if (agg == MVX_AGG_SUM) launch_stream<MVX_AGG_SUM>(c, c.B);
+                else launch_stream<MVX_AGG_MAX>(c, c.B);
+            });
+            compare(c, "streaming");
+        }
+    }
+    return 0;
+}
