@@ -549,15 +549,6 @@ struct BrickShared {
 
 #ifdef MVX_BRICK_STATS  // development builds only (tools/brick_stats.hip)
 __device__ unsigned brick_stats[4];  // bricks, bricks on the direct path, bricks whose patches do not fit, max rows
-__device__ unsigned long long brick_phase[8];  // summed s_memtime deltas of wave 0 between the kernel's phases
-#define MVX_STAMP(i)                                                                    \
-    do {                                                                                \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                   \
-        if (tid == 0) atomicAdd(&brick_phase[i], now_ - stamp_);                        \
-        stamp_ = now_;                                                                  \
-    } while (0)
-#else
-#define MVX_STAMP(i)
 #endif
 
 
@@ -608,7 +599,7 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], int lane) {
     }
 }
 
-template <int AGG, bool GRID, bool UNITS = true>
+template <int AGG, bool GRID, int NV>
 __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const float* __restrict__ feat_cl,
                                                                        const float* __restrict__ proj,
                                                                        VoxelSource coord,
@@ -616,6 +607,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
                                                                        int vx, int vy, int vz, FastDiv bricks_per_frame,
                                                                        FastDiv nbz, FastDiv nby, double sx, double sy,
                                                                        float* __restrict__ vol) {
+    static_assert(NV >= 2 && NV <= 4, "two to four views (the library launches three and four)");
     constexpr int C = 32;
     extern __shared__ __align__(128) unsigned char smem[];
     BrickShared* sh = reinterpret_cast<BrickShared*>(smem + 2 * kPatchBytes);
@@ -646,12 +638,9 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
     const int64_t n_vox = static_cast<int64_t>(vx) * vy * vz;
     const int64_t n = (static_cast<int64_t>(bx * kBrick + lx) * vy + by * kBrick + ly) * vz + bz * kBrick + lz;
     const size_t img_stride = static_cast<size_t>(H) * W * C;
-    const float* fb = feat_cl + b * 4 * img_stride;
+    const float* fb = feat_cl + b * NV * img_stride;
 
-#ifdef MVX_BRICK_STATS
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#endif
-    if (tid < 48) sh->cam[tid] = camera_entry(proj + b * 48 + (tid / 12) * 12, tid % 12, sx, sy);
+    if (tid < NV * 12) sh->cam[tid] = camera_entry(proj + b * NV * 12 + (tid / 12) * 12, tid % 12, sx, sy);
     if (tid == 64) {
         sh->bad = 0;
         sh->redo = 0;
@@ -679,31 +668,33 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
         }
     };
     load_position(lz);
-    float4 wt[4];
-    int txb[4], tyb[4];
-    int ox[4], oy[4], rows[4];
-    unsigned a0[4], a1[4];  // LDS addresses of the taps' two rows (see patch_taps)
+    float4 wt[NV];
+    int txb[NV], tyb[NV];
+    int ox[NV], oy[NV], rows[NV];
+    unsigned a0[NV], a1[NV];  // LDS addresses of the taps' two rows (see patch_taps)
     bool fits = true, inside = true;
     const bool corner = (lx == 0 || lx == kBrick - 1) && (ly == 0 || ly == kBrick - 1) && (lz == 0 || lz == kBrick - 1);
     const int corner_id = ((lx & 4) | (ly & 2) | (lz & 1));  // for lx, ly, lz in {0, 7}
 
-    // projects the two views of a pass; the corner voxels leave their floor positions for everybody
+    // projects the (up to) two views of a pair; the corner voxels leave their floor positions for everybody
     auto project_pair = [&](int pass) {
 #pragma unroll
         for (int vv = 0; vv < 2; ++vv) {
             const int v = pass * 2 + vv;
-            const TapXY t = project_tap_xy(sh->cam + v * 12, X, Y, Z, H, W, AGG == MVX_AGG_SOFTMAX ? kLog2e : 1.0f);
-            wt[v] = make_float4(t.w00, t.w01, t.w10, t.w11);
-            txb[v] = t.xb;
-            tyb[v] = t.yb;
-            if (corner) {
-                sh->corner[v][0][corner_id] = t.behind ? INT_MAX : t.x0;
-                sh->corner[v][1][corner_id] = t.y0;
+            if (v < NV) {
+                const TapXY t = project_tap_xy(sh->cam + v * 12, X, Y, Z, H, W, AGG == MVX_AGG_SOFTMAX ? kLog2e : 1.0f);
+                wt[v] = make_float4(t.w00, t.w01, t.w10, t.w11);
+                txb[v] = t.xb;
+                tyb[v] = t.yb;
+                if (corner) {
+                    sh->corner[v][0][corner_id] = t.behind ? INT_MAX : t.x0;
+                    sh->corner[v][1][corner_id] = t.y0;
+                }
             }
         }
     };
-    // patch rectangles of the two views (wave-uniform): minimum and maximum over each group of 8 lanes holding the
-    // 8 corners of one (view, axis); then the per-lane check and the tap addresses
+    // patch rectangles of the views of a pair (wave-uniform): minimum and maximum over each group of 8 lanes holding
+    // the 8 corners of one (view, axis); then the per-lane check and the tap addresses.  View v lives in buffer v & 1.
     auto rectangles_pair = [&](int pass) {
         int cmin = reinterpret_cast<const int*>(sh->corner)[pass * 32 + (lane & 31)], cmax = cmin;
         cmin = min(cmin, dpp_movi<0xB1>(cmin));
@@ -715,97 +706,96 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
 #pragma unroll
         for (int vv = 0; vv < 2; ++vv) {
             const int v = pass * 2 + vv;
-            const int minx = __builtin_amdgcn_readlane(cmin, vv * 16), miny = __builtin_amdgcn_readlane(cmin, vv * 16 + 8);
-            const int maxx = __builtin_amdgcn_readlane(cmax, vv * 16), maxy = __builtin_amdgcn_readlane(cmax, vv * 16 + 8);
-            ox[v] = min(max(minx, 0), W - 2);
-            oy[v] = min(max(miny, 0), H - 2);
-            const int ex = min(max(maxx, 0), W - 2) + 1, ey = min(max(maxy, 0), H - 2) + 1;  // last column / row read
-            rows[v] = ey - oy[v] + 1;
-            // a corner behind the camera reads as INT_MAX: no patch
-            fits = fits && (maxx != INT_MAX) && (ex - ox[v] + 1 <= kPatchW) && (rows[v] <= kPatchRows);
-            const unsigned any = __builtin_bit_cast(unsigned, wt[v].x) | __builtin_bit_cast(unsigned, wt[v].y) |
-                                 __builtin_bit_cast(unsigned, wt[v].z) | __builtin_bit_cast(unsigned, wt[v].w);
-            // voxels whose weights are all zero read the patch origin (always staged) instead of wherever the clamp went
-            const int rx = any ? txb[v] - ox[v] : 0, ry = any ? tyb[v] - oy[v] : 0;
-            inside = inside && rx >= 0 && rx + 1 < kPatchW && ry >= 0 && ry + 1 < rows[v];
-            const unsigned pixel = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_byte*)(smem))) + vv * kPatchBytes +
-                                   static_cast<unsigned>(ry * kPatchW + rx) * kPixelBytes;
-            a0[v] = pixel + (static_cast<unsigned>(ry & 7) << 4);
-            a1[v] = pixel + kPatchW * kPixelBytes + (static_cast<unsigned>((ry + 1) & 7) << 4);
+            if (v < NV) {
+                const int minx = __builtin_amdgcn_readlane(cmin, vv * 16), miny = __builtin_amdgcn_readlane(cmin, vv * 16 + 8);
+                const int maxx = __builtin_amdgcn_readlane(cmax, vv * 16), maxy = __builtin_amdgcn_readlane(cmax, vv * 16 + 8);
+                ox[v] = min(max(minx, 0), W - 2);
+                oy[v] = min(max(miny, 0), H - 2);
+                const int ex = min(max(maxx, 0), W - 2) + 1, ey = min(max(maxy, 0), H - 2) + 1;  // last column / row read
+                rows[v] = ey - oy[v] + 1;
+                // a corner behind the camera reads as INT_MAX: no patch
+                fits = fits && (maxx != INT_MAX) && (ex - ox[v] + 1 <= kPatchW) && (rows[v] <= kPatchRows);
+                const unsigned any = __builtin_bit_cast(unsigned, wt[v].x) | __builtin_bit_cast(unsigned, wt[v].y) |
+                                     __builtin_bit_cast(unsigned, wt[v].z) | __builtin_bit_cast(unsigned, wt[v].w);
+                // voxels whose weights are all zero read the patch origin (always staged) instead of wherever the clamp went
+                const int rx = any ? txb[v] - ox[v] : 0, ry = any ? tyb[v] - oy[v] : 0;
+                inside = inside && rx >= 0 && rx + 1 < kPatchW && ry >= 0 && ry + 1 < rows[v];
+                const unsigned pixel = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_byte*)(smem))) + vv * kPatchBytes +
+                                       static_cast<unsigned>(ry * kPatchW + rx) * kPixelBytes;
+                a0[v] = pixel + (static_cast<unsigned>(ry & 7) << 4);
+                a1[v] = pixel + kPatchW * kPixelBytes + (static_cast<unsigned>((ry + 1) & 7) << 4);
+            }
         }
     };
-    // starts the copies of the two patches of a pass: rows of 16 pixels, half a row per wave-instruction
-    auto stage_pair = [&](int pass) {
+    // starts the copy of the patch of view v into buffer v & 1: rows of 16 pixels, half a row per wave-instruction
+    auto stage_one = [&](int v) {
+        global_byte* img = (global_byte*)(fb + v * img_stride);
+        lds_byte* dst = (lds_byte*)(smem) + (v & 1) * kPatchBytes;
 #pragma unroll
-        for (int vv = 0; vv < 2; ++vv) {
-            const int v = pass * 2 + vv;
-            global_byte* img = (global_byte*)(fb + v * img_stride);
-            lds_byte* dst = (lds_byte*)(smem) + vv * kPatchBytes;
-#pragma unroll
-            for (int it = 0; it < kPatchRows / 4; ++it) {
-                const int py = it * 4 + (wave >> 1);  // wave-uniform
-                if (py < rows[v]) {
-                    const int px = ((wave & 1) << 3) + (lane >> 3);
-                    const int q = (lane & 7) ^ (py & 7);
-                    const int gx = min(ox[v] + px, W - 1), gy = oy[v] + py;
-                    const unsigned src = (static_cast<unsigned>(gy * W + gx) * C + static_cast<unsigned>(q) * 4u) * 4u;
-                    __builtin_amdgcn_global_load_lds(img + src, dst + (py * kPatchW + ((wave & 1) << 3)) * kPixelBytes,
-                                                     16, 0, 0);
-                }
+        for (int it = 0; it < kPatchRows / 4; ++it) {
+            const int py = it * 4 + (wave >> 1);  // wave-uniform
+            if (py < rows[v]) {
+                const int px = ((wave & 1) << 3) + (lane >> 3);
+                const int q = (lane & 7) ^ (py & 7);
+                const int gx = min(ox[v] + px, W - 1), gy = oy[v] + py;
+                const unsigned src = (static_cast<unsigned>(gy * W + gx) * C + static_cast<unsigned>(q) * 4u) * 4u;
+                __builtin_amdgcn_global_load_lds(img + src, dst + (py * kPatchW + ((wave & 1) << 3)) * kPixelBytes, 16,
+                                                 0, 0);
             }
         }
     };
 
     project_pair(0);
-    MVX_STAMP(0);  // set-up + projection of views 0, 1
     __syncthreads();
-    MVX_STAMP(1);  // wait at the barrier
     rectangles_pair(0);
-    const bool fits01 = fits;
-    if (fits01) stage_pair(0);  // harmless if a lane turns out not to fit: the vote below decides who reads
-    MVX_STAMP(2);  // rectangles + copy issue (pass 0)
-    project_pair(1);
-    MVX_STAMP(3);  // projection of views 2, 3 (the copies are in flight)
+    if (fits) {  // harmless if a lane turns out not to fit: the vote below decides who reads
+        stage_one(0);
+        stage_one(1);
+    }
+    if (NV > 2) project_pair(1);  // (the copies are in flight)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    MVX_STAMP(4);  // wait for the copies
-    rectangles_pair(1);
+    if (NV > 2) rectangles_pair(1);
     if (!inside) sh->bad = 1;
     __syncthreads();
     const bool staged = fits && (sh->bad == 0);
 
-    // voxel of lane (lane & ~3), channel (lane & 3) of a quad: where this lane's 16-byte store of pass 1 starts
+    // voxel of lane (lane & ~3), channel (lane & 3) of a quad: where this lane's 16-byte stores start
     const int64_t quad_off = b * C * n_vox + (n - (lane & 3)) + static_cast<int64_t>(lane & 3) * n_vox;
 #ifdef MVX_BRICK_STATS  // development builds only (tools/brick_stats.hip): how many bricks leave the staged path, and why
     if (tid == 0) {
         atomicAdd(&brick_stats[0], 1u);
         if (!staged) atomicAdd(&brick_stats[1], 1u);
         if (!fits) atomicAdd(&brick_stats[2], 1u);
-        atomicMax(&brick_stats[3], static_cast<unsigned>(max(max(rows[0], rows[1]), max(rows[2], rows[3]))));
+        int most = rows[0];
+#pragma unroll
+        for (int v = 1; v < NV; ++v) most = max(most, rows[v]);
+        atomicMax(&brick_stats[3], static_cast<unsigned>(most));
     }
 #endif
     // Direct path: taps from global memory with the tile kernel's access shape -- 8 lanes per voxel, each fetching
-    // its 16 bytes of whole 128-byte lines -- and the same arithmetic.  The weights and tap pixels change lanes
-    // through tables in the (unused) patch area; slots are ordered so that the 8 voxels of a step are consecutive
-    // along z.
+    // its 16 bytes of whole 128-byte lines -- and the tile kernel's arithmetic (four views: all loads of a step in
+    // flight together and the shifted softmax; two or three: view by view).  The weights and tap pixels change
+    // lanes through tables in the (unused) patch area; slots are ordered so that the 8 voxels of a step are
+    // consecutive along z.
     auto direct_path = [&]() __attribute__((always_inline)) {
-        float4* wts = reinterpret_cast<float4*>(smem);                                          // [4][512]
-        unsigned* pix = reinterpret_cast<unsigned*>(smem + 4 * kBrickThreads * sizeof(float4));  // [4][512]
-        unsigned* vox = pix + 4 * kBrickThreads;                                                // [512]
+        float4* wts = reinterpret_cast<float4*>(smem);                                            // [NV][512]
+        unsigned* pix = reinterpret_cast<unsigned*>(smem + NV * kBrickThreads * sizeof(float4));  // [NV][512]
+        unsigned* vox = pix + NV * kBrickThreads;                                                 // [512]
         const int slot = wave * 64 + ly * kBrick + lz;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < NV; ++v) {
             wts[v * kBrickThreads + slot] = wt[v];
             pix[v * kBrickThreads + slot] = static_cast<unsigned>(tyb[v] * W + txb[v]);
         }
         vox[slot] = static_cast<unsigned>(n);
         __syncthreads();
         const int q = lane & 7;
-        float cc[4][4] = {};
+        float cc[NV][4] = {};
         if (AGG == MVX_AGG_CONF) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * 4 + v) * C + q * 4);
+            for (int v = 0; v < NV; ++v) {
+                const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * NV + v) * C + q * 4);
                 cc[v][0] = c4.x;
                 cc[v][1] = c4.y;
                 cc[v][2] = c4.z;
@@ -815,21 +805,41 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
 #pragma unroll 1
         for (int step = 0; step < 8; ++step) {
             const int t = wave * 64 + step * 8 + (lane >> 3);
-            float4 w4[4];
-            Taps4 f[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                w4[v] = wts[v * kBrickThreads + t];
-                f[v] = load_taps(fb + v * img_stride, pix[v * kBrickThreads + t], W, C, q);
-            }
-            float val[4][4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) interpolate(f[v], w4[v], val[v]);
             float* dst = vol + b * C * n_vox + vox[t];
+            if constexpr (NV == 4) {
+                float4 w4[NV];
+                Taps4 f[NV];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                dst[static_cast<int64_t>(q * 4 + k) * n_vox] = combine_four<AGG>(
-                    val[0][k], val[1][k], val[2][k], val[3][k], cc[0][k], cc[1][k], cc[2][k], cc[3][k]);
+                for (int v = 0; v < NV; ++v) {
+                    w4[v] = wts[v * kBrickThreads + t];
+                    f[v] = load_taps(fb + v * img_stride, pix[v * kBrickThreads + t], W, C, q);
+                }
+                float val[NV][4];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) interpolate(f[v], w4[v], val[v]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    dst[static_cast<int64_t>(q * 4 + k) * n_vox] = combine_four<AGG>(
+                        val[0][k], val[1][k], val[2][k], val[NV - 1][k], cc[0][k], cc[1][k], cc[2][k], cc[NV - 1][k]);
+            } else {
+                Aggregator<AGG> agg;
+                agg.init();
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 w4 = wts[v * kBrickThreads + t];
+                    Tap tap;
+                    tap.w00 = w4.x;
+                    tap.w01 = w4.y;
+                    tap.w10 = w4.z;
+                    tap.w11 = w4.w;
+                    tap.pixel = pix[v * kBrickThreads + t];
+                    float val[4];
+                    sample4(fb + v * img_stride, tap, W, C, q, val);
+                    agg.add(val, cc[v]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[static_cast<int64_t>(q * 4 + k) * n_vox] = agg.result(k);
+            }
         }
     };
     if (!staged) {
@@ -837,201 +847,100 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
         return;
     }
 
-    if (UNITS) {
-        // 3./4. four units of one view each.  View v lives in buffer v & 1: while unit 0 (1) is sampled the patch
-        // of view 2 (3) is on its way into the buffer that unit has just left, so no wave waits for a copy that
-        // has just been issued.  The views are aggregated one at a time in registers.  sum / conf / max: the same
-        // operations in the same order as the tile kernel (bit-identical).  The view softmax
-        // sum_v x_v e^{x_v} / sum_v e^{x_v} is accumulated without subtracting the maximum over views -- two
-        // registers per channel, no second look at the values -- which is the same quotient as long as no term
-        // overflows and the largest term is not flushed.  That is checked, not assumed: every denominator must lie
-        // in [2^-80, 2^100] (a term below 2^-46 of the largest may then have been lost to underflow at most); a
-        // brick that fails the check is computed again by the direct path, which evaluates the shifted form.
-        // Results differ from the shifted form by the rounding of the exponentials only (a few float32 ulps).
-        auto stage_one = [&](int v) {
-            global_byte* img = (global_byte*)(fb + v * img_stride);
-            lds_byte* dst = (lds_byte*)(smem) + (v & 1) * kPatchBytes;
+    // 3./4. one unit per view.  View v lives in buffer v & 1: while unit v - 1 is sampled the patch of view v + 1 is
+    // on its way into the buffer that unit v - 2 has left, so no wave waits for a copy that has just been issued.
+    // The views are aggregated one at a time in registers.  sum / conf / max: the same operations in the same order
+    // as the tile kernel (bit-identical).  The view softmax sum_v x_v e^{x_v} / sum_v e^{x_v} is accumulated without
+    // subtracting the maximum over views -- two registers per channel, no second look at the values -- which is the
+    // same quotient as long as no term overflows and the largest term is not flushed.  That is checked, not assumed:
+    // every denominator must lie in [2^-80, 2^100] (a term below 2^-46 of the largest may then have been lost to
+    // underflow at most); a brick that fails the check is computed again by the direct path, which evaluates the
+    // shifted form.  Results differ from the shifted form by the rounding of the exponentials only (a few float32
+    // ulps).
+    float2v acc[C / 2];  // sum / conf / max: the aggregate; softmax: the numerator
+    float2v den[AGG == MVX_AGG_SOFTMAX ? C / 2 : 1];
+    float2v chk_d = {0.0f, 0.0f}, chk_r = {0.0f, 0.0f};
 #pragma unroll
-            for (int it = 0; it < kPatchRows / 4; ++it) {
-                const int py = it * 4 + (wave >> 1);  // wave-uniform
-                if (py < rows[v]) {
-                    const int px = ((wave & 1) << 3) + (lane >> 3);
-                    const int q = (lane & 7) ^ (py & 7);
-                    const int gx = min(ox[v] + px, W - 1), gy = oy[v] + py;
-                    const unsigned src = (static_cast<unsigned>(gy * W + gx) * C + static_cast<unsigned>(q) * 4u) * 4u;
-                    __builtin_amdgcn_global_load_lds(img + src, dst + (py * kPatchW + ((wave & 1) << 3)) * kPixelBytes,
-                                                     16, 0, 0);
-                }
-            }
-        };
-        float2v acc[C / 2];  // sum / conf / max: the aggregate; softmax: the numerator
-        float2v den[AGG == MVX_AGG_SOFTMAX ? C / 2 : 1];
-        float2v chk_d = {0.0f, 0.0f}, chk_r = {0.0f, 0.0f};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            if (v == 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every lane has read view 0
-                stage_one(2);
-            } else if (v == 2) {
-                // this wave's copies of view 2 have landed; then: everybody's have, and every lane has read view 1
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                stage_one(3);
-            } else if (v == 3) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float2v val[2];
-                const Taps4 f = patch_taps(a0[v], a1[v], q);
-                interpolate_x2(f, wt[v], val[0], val[1]);
-                float2v cc[2] = {};
-                if (AGG == MVX_AGG_CONF) {
-                    const float* cv = vconf + (b * 4 + v) * C + q * 4;
-                    cc[0] = float2v{cv[0], cv[1]};
-                    cc[1] = float2v{cv[2], cv[3]};
-                }
-                float res[4];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int cp = q * 2 + h;  // channel pair
-                    if (AGG == MVX_AGG_SUM) {
-                        acc[cp] = v == 0 ? val[h] : acc[cp] + val[h];
-                    } else if (AGG == MVX_AGG_CONF) {
-                        acc[cp] = v == 0 ? val[h] * cc[h] : __builtin_elementwise_fma(val[h], cc[h], acc[cp]);
-                    } else if (AGG == MVX_AGG_MAX) {
-                        acc[cp] = v == 0 ? val[h] : float2v{fmaxf(acc[cp].x, val[h].x), fmaxf(acc[cp].y, val[h].y)};
-                    } else {
-                        const float2v e = {__builtin_amdgcn_exp2f(val[h].x), __builtin_amdgcn_exp2f(val[h].y)};
-                        den[cp] = v == 0 ? e : den[cp] + e;
-                        acc[cp] = v == 0 ? e * val[h] : __builtin_elementwise_fma(e, val[h], acc[cp]);
-                    }
-                    // pin the running values here: left alone, the compiler sinks the interpolation towards the next
-                    // unit and carries the raw taps (four times as many registers) instead
-                    asm volatile("" : "+v"(acc[cp]));
-                    if (AGG == MVX_AGG_SOFTMAX) asm volatile("" : "+v"(den[cp]));
-                    if (v == 3) {
-                        float2v r = acc[cp];
-                        if (AGG == MVX_AGG_SOFTMAX) {
-                            const float2v rden = {__builtin_amdgcn_rcpf(den[cp].x), __builtin_amdgcn_rcpf(den[cp].y)};
-                            chk_d = chk_d + den[cp];
-                            chk_r = chk_r + rden;
-                            r = r * rden * float2v{kLn2, kLn2};
-                        }
-                        res[h * 2] = r.x;
-                        res[h * 2 + 1] = r.y;
-                    }
-                }
-                if (v == 3) {
-                    // the four lanes of a quad hold four consecutive voxels along z: after the transpose each lane
-                    // stores one channel of all four with a single 16-byte store
-                    quad_transpose(res, lane);
-                    *reinterpret_cast<float4*>(vol + quad_off + static_cast<int64_t>(q * 4) * n_vox) =
-                        make_float4(res[0], res[1], res[2], res[3]);
-                }
-                // keep the quads in order: hoisting the reads of later quads would need hundreds of registers
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
+    for (int v = 0; v < NV; ++v) {
+        if (v >= 2) {
+            // this wave's copies of view v have landed; then: everybody's have, and every lane has read view v - 1
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (v + 1 < NV) stage_one(v + 1);
+        } else if (v == 1 && NV > 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every lane has read view 0
+            stage_one(2);
         }
-        if (AGG == MVX_AGG_SOFTMAX) {
-            // every denominator in [2^-80, 2^100] (a NaN fails both comparisons)
-            if (!(chk_d.x + chk_d.y <= 0x1p100f) || !(chk_r.x + chk_r.y <= 0x1p80f)) sh->redo = 1;
-            // The stores above have left this wave before anybody stores the same voxels again.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (sh->redo != 0) {
-                // weights and tap pixels once more (rather than kept in registers through the sampling above)
-                int lz_again = lz;
-                asm volatile("" : "+v"(lz_again));
-                load_position(lz_again);
-                project_pair(0);
-                project_pair(1);
-                direct_path();
-            }
-        }
-        return;
-    }
-
-    // 3./4. two passes of two views
-    // what pass 1 leaves for pass 2: both views' values for the softmax, their partial aggregate otherwise
-    constexpr int kKeep = (AGG == MVX_AGG_SOFTMAX) ? 2 : 1;
-    float2v keep[kKeep][C / 2];  // channel pairs
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
-            __syncthreads();  // every lane has read the patches of pass 0
-            stage_pair(1);
-            MVX_STAMP(5);  // barrier + copy issue (pass 1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            MVX_STAMP(6);  // wait for the copies
-        }
+        constexpr int kLast = NV - 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            float2v val[2][2];  // [view of the pass][channel pair of the quad]
-#pragma unroll
-            for (int vv = 0; vv < 2; ++vv) {
-                const int v = pass * 2 + vv;
-                const Taps4 f = patch_taps(a0[v], a1[v], q);
-                interpolate_x2(f, wt[v], val[vv][0], val[vv][1]);
-            }
-            float2v cc[4][2] = {};
+            float2v val[2];
+            const Taps4 f = patch_taps(a0[v], a1[v], q);
+            interpolate_x2(f, wt[v], val[0], val[1]);
+            float2v cc[2] = {};
             if (AGG == MVX_AGG_CONF) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float* cv = vconf + (b * 4 + v) * C + q * 4;
-                    cc[v][0] = float2v{cv[0], cv[1]};
-                    cc[v][1] = float2v{cv[2], cv[3]};
-                }
+                const float* cv = vconf + (b * NV + v) * C + q * 4;
+                cc[0] = float2v{cv[0], cv[1]};
+                cc[1] = float2v{cv[2], cv[3]};
             }
-            float res[4];  // the four channels of the quad (pass 1)
+            float res[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int cp = q * 2 + h;  // channel pair
-                if (pass == 0) {
-                    if (AGG == MVX_AGG_SOFTMAX) {
-                        keep[0][cp] = val[0][h];
-                        keep[kKeep - 1][cp] = val[1][h];
-                    } else if (AGG == MVX_AGG_SUM) {
-                        keep[0][cp] = val[0][h] + val[1][h];
-                    } else if (AGG == MVX_AGG_CONF) {
-                        keep[0][cp] = __builtin_elementwise_fma(val[1][h], cc[1][h], val[0][h] * cc[0][h]);
-                    } else {
-                        keep[0][cp] = float2v{fmaxf(val[0][h].x, val[1][h].x), fmaxf(val[0][h].y, val[1][h].y)};
-                    }
-                    // pin the values here: left alone, the compiler sinks the interpolation into pass 2 and carries
-                    // the raw taps (four times as many registers) across the barrier instead
-                    asm volatile("" : "+v"(keep[0][cp]));
-                    if (kKeep == 2) asm volatile("" : "+v"(keep[kKeep - 1][cp]));
+                if (AGG == MVX_AGG_SUM) {
+                    acc[cp] = v == 0 ? val[h] : acc[cp] + val[h];
+                } else if (AGG == MVX_AGG_CONF) {
+                    acc[cp] = v == 0 ? val[h] * cc[h] : __builtin_elementwise_fma(val[h], cc[h], acc[cp]);
+                } else if (AGG == MVX_AGG_MAX) {
+                    // (the tile kernel starts two or three views from -infinity, which is not the identity for a NaN)
+                    const float2v prev = v == 0 ? float2v{-INFINITY, -INFINITY} : acc[cp];
+                    acc[cp] = (v == 0 && NV == 4) ? val[h] : float2v{fmaxf(prev.x, val[h].x), fmaxf(prev.y, val[h].y)};
                 } else {
-                    float2v r;
+                    const float2v e = {__builtin_amdgcn_exp2f(val[h].x), __builtin_amdgcn_exp2f(val[h].y)};
+                    den[cp] = v == 0 ? e : den[cp] + e;
+                    acc[cp] = v == 0 ? e * val[h] : __builtin_elementwise_fma(e, val[h], acc[cp]);
+                }
+                // pin the running values here: left alone, the compiler sinks the interpolation towards the next
+                // unit and carries the raw taps (four times as many registers) instead
+                asm volatile("" : "+v"(acc[cp]));
+                if (AGG == MVX_AGG_SOFTMAX) asm volatile("" : "+v"(den[cp]));
+                if (v == kLast) {
+                    float2v r = acc[cp];
                     if (AGG == MVX_AGG_SOFTMAX) {
-                        const float2v z = {0.0f, 0.0f};
-                        r = combine_four_x2<AGG>(keep[0][cp], keep[kKeep - 1][cp], val[0][h], val[1][h], z, z, z, z);
-                    } else if (AGG == MVX_AGG_SUM) {
-                        r = (keep[0][cp] + val[0][h]) + val[1][h];
-                    } else if (AGG == MVX_AGG_CONF) {
-                        r = __builtin_elementwise_fma(val[1][h], cc[3][h], __builtin_elementwise_fma(val[0][h], cc[2][h], keep[0][cp]));
-                    } else {
-                        r = float2v{fmaxf(keep[0][cp].x, fmaxf(val[0][h].x, val[1][h].x)),
-                                    fmaxf(keep[0][cp].y, fmaxf(val[0][h].y, val[1][h].y))};
+                        const float2v rden = {__builtin_amdgcn_rcpf(den[cp].x), __builtin_amdgcn_rcpf(den[cp].y)};
+                        chk_d = chk_d + den[cp];
+                        chk_r = chk_r + rden;
+                        r = r * rden * float2v{kLn2, kLn2};
                     }
                     res[h * 2] = r.x;
                     res[h * 2 + 1] = r.y;
                 }
             }
-            if (pass == 1) {
-                // the four lanes of a quad hold four consecutive voxels along z: after the transpose each lane stores
-                // one channel of all four with a single 16-byte store
+            if (v == kLast) {
+                // the four lanes of a quad hold four consecutive voxels along z: after the transpose each lane
+                // stores one channel of all four with a single 16-byte store
                 quad_transpose(res, lane);
                 *reinterpret_cast<float4*>(vol + quad_off + static_cast<int64_t>(q * 4) * n_vox) =
                     make_float4(res[0], res[1], res[2], res[3]);
             }
-            // keep the quads in order: hoisting the reads of later quads above this point would need hundreds of
-            // registers
+            // keep the quads in order: hoisting the reads of later quads would need hundreds of registers
             __builtin_amdgcn_sched_barrier(0);
         }
-        MVX_STAMP(7);  // sampling (both passes)
+    }
+    if (AGG == MVX_AGG_SOFTMAX) {
+        // every denominator in [2^-80, 2^100] (a NaN fails both comparisons)
+        if (!(chk_d.x + chk_d.y <= 0x1p100f) || !(chk_r.x + chk_r.y <= 0x1p80f)) sh->redo = 1;
+        // The stores above have left this wave before anybody stores the same voxels again.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (sh->redo != 0) {
+            // weights and tap pixels once more (rather than kept in registers through the sampling above)
+            int lz_again = lz;
+            asm volatile("" : "+v"(lz_again));
+            load_position(lz_again);
+            project_pair(0);
+            if (NV > 2) project_pair(1);
+            direct_path();
+        }
     }
 }
 
@@ -1123,9 +1032,11 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
     const int p_tiles = (HW + 63) / 64, c_tiles = (Cp + 31) / 32;
     const bool tiled = (C == 32) && (V <= kTileMaxViews) && (n_voxels % kTile == 0) && aligned16(volumes) &&
                        (aggregation != MVX_AGG_CONF || aligned16(vol_conf));
-    // the brick kernel: four views of 32 channels into a grid whose sides are multiples of 8 (the reference's
-    // 4-camera, 64^3 set-up); other shapes take the tile or the any-shape kernel
-    const bool bricked = (C == 32) && (V == 4) && (vx % kBrick == 0) && (vy % kBrick == 0) && (vz % kBrick == 0) &&
+    // the brick kernel: three or four views of 32 channels into a grid whose sides are multiples of 8 (the reference's
+    // 64^3 set-up; its collate function draws 2 to 4 cameras).  Two views are left to the tile kernel, which is the
+    // faster one there (0.87 against 0.94 ms per 64 frames: two units do not amortise a brick's set-up); other shapes
+    // take the tile or the any-shape kernel.
+    const bool bricked = (C == 32) && (V == 3 || V == 4) && (vx % kBrick == 0) && (vy % kBrick == 0) && (vz % kBrick == 0) &&
                          (static_cast<int64_t>(h) * w * C * 4 < (1LL << 31)) && (n_voxels < (1LL << 32)) &&
                          aligned16(volumes) &&
                          (aggregation != MVX_AGG_CONF || aligned16(vol_conf)) &&
@@ -1173,19 +1084,26 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
             const FastDiv d_bricks = fast_divisor(static_cast<unsigned>(bricks));
             const FastDiv d_nbz = fast_divisor(static_cast<unsigned>(vz / kBrick));
             const FastDiv d_nby = fast_divisor(static_cast<unsigned>(vy / kBrick));
-#define MVX_LAUNCH_BRICK(AGG)                                                                                      \
-    if (cd.has_grid)                                                                                              \
-        hipLaunchKernelGGL((unproject_brick32<AGG, true>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, \
-                           vc, h, w, vx, vy, vz, d_bricks, d_nbz, d_nby, sx, sy, vo);                             \
-    else                                                                                                          \
-        hipLaunchKernelGGL((unproject_brick32<AGG, false>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, \
+#define MVX_LAUNCH_BRICK_NV(AGG, NV)                                                                                   \
+    if (cd.has_grid)                                                                                                    \
+        hipLaunchKernelGGL((unproject_brick32<AGG, true, NV>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, \
+                           vc, h, w, vx, vy, vz, d_bricks, d_nbz, d_nby, sx, sy, vo);                                   \
+    else                                                                                                                \
+        hipLaunchKernelGGL((unproject_brick32<AGG, false, NV>), grid, dim3(kBrickThreads), brick_smem, st, feat_cl, pj, cd, \
                            vc, h, w, vx, vy, vz, d_bricks, d_nbz, d_nby, sx, sy, vo)
+#define MVX_LAUNCH_BRICK(AGG)                      \
+    if (V == 4) {                                  \
+        MVX_LAUNCH_BRICK_NV(AGG, 4);               \
+    } else {                                       \
+        MVX_LAUNCH_BRICK_NV(AGG, 3);               \
+    }
             switch (aggregation) {
                 case MVX_AGG_SUM: MVX_LAUNCH_BRICK(MVX_AGG_SUM); break;
                 case MVX_AGG_CONF: MVX_LAUNCH_BRICK(MVX_AGG_CONF); break;
                 case MVX_AGG_MAX: MVX_LAUNCH_BRICK(MVX_AGG_MAX); break;
                 default: MVX_LAUNCH_BRICK(MVX_AGG_SOFTMAX); break;
             }
+#undef MVX_LAUNCH_BRICK_NV
 #undef MVX_LAUNCH_BRICK
         } else if (tiled) {
             const int64_t tiles = n_voxels / kTile;

@@ -344,16 +344,19 @@ def no_bricks():
     lib.mvx_set_kernel_selection(0)
 
 
-@pytest.mark.parametrize("side,shape", [(2500.0, (64, 64, 64)), (2500.0, (16, 8, 24)), (9000.0, (32, 32, 32)),
-                                        (30000.0, (32, 32, 32)), (600.0, (32, 32, 32))])
-def test_unproject_brick_kernel_equals_tile_kernel(side, shape, no_bricks):
+@pytest.mark.parametrize("side,shape,views", [(2500.0, (64, 64, 64), 4), (2500.0, (16, 8, 24), 4), (9000.0, (32, 32, 32), 4),
+                                              (30000.0, (32, 32, 32), 4), (600.0, (32, 32, 32), 4),
+                                              (2500.0, (64, 64, 64), 2), (2500.0, (64, 64, 64), 3), (9000.0, (32, 32, 32), 3),
+                                              (30000.0, (16, 8, 24), 2)])
+def test_unproject_brick_kernel_equals_tile_kernel(side, shape, views, no_bricks):
     """The brick kernel (patches of the maps staged in LDS) and the tile kernel (taps from global memory) share
     their arithmetic: bit-identical volumes for sum, conf and max.  The brick kernel accumulates the view softmax
     without subtracting the maximum over views (checked per brick, with the shifted form as the fallback), which
     differs from the tile kernel's shifted form by the rounding of the exponentials: a few float32 ulps.
     2.5 m: the reference's cuboid; 9 m and 30 m: bricks whose patches exceed 16 x 16 pixels or that straddle / miss
-    the maps (direct path inside the brick kernel); 0.6 m: many voxels per pixel."""
-    case = synth.volumetric_case(23, 2, 4, volume_size=64, cuboid_side=side, with_volumes=False)
+    the maps (direct path inside the brick kernel); 0.6 m: many voxels per pixel.  Two, three and four views (the
+    reference's collate function draws 2 to 4 cameras per sample)."""
+    case = synth.volumetric_case(23, 2, views, volume_size=64, cuboid_side=side, with_volumes=False)
     feats, proj, vconf = (to_dev(case[k]) for k in ("features", "proj", "vol_confidences"))
     coord = to_dev(np.ascontiguousarray(case["coord_volumes"][:, :shape[0], :shape[1], :shape[2]]))
     for method in ("sum", "conf", "max", "softmax"):
@@ -377,7 +380,7 @@ def test_unproject_brick_kernel_equals_tile_kernel(side, shape, no_bricks):
     # ... and a batch in which only a few voxels are out of range
     some = feats.clone()
     some[0, 1, 3, 40:56, 40:56] = 250.0
-    some[1, 2, 7, 30:50, 30:50] = -400.0
+    some[1, views - 1, 7, 30:50, 30:50] = -400.0
     no_bricks(False)
     brick_some = op.unproject_heatmaps(some, proj, coord, "softmax", vconf)
     no_bricks(True)

@@ -31,7 +31,7 @@ print("grid volume equals the synthetic one:", bool(torch.equal(gcoord, coord)))
 
 
 def timeit(fn, n=20):
-    for _ in range(3):
+    for _ in range(10):   # the clocks ramp up over the first launches after an idle spell
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -57,3 +57,19 @@ for name, mask in (("default kernels", 0), ("without the brick and resident kern
     print("  soft-argmax 3-D coords only, volume %.3f ms" % timeit(lambda: op.integrate_tensor_3d_with_coordinates(vols, coord, return_volumes=False)))
     print("  soft-argmax 3-D coords only, grid   %.3f ms" % timeit(lambda: op.integrate_tensor_3d_with_coordinates(vols, gcoord, return_volumes=False)))
 lib.mvx_set_kernel_selection(0)
+
+
+# the unprojection for other numbers of views (channel-last maps, grid parameters): brick kernel for 2 to 4 views,
+# tile kernel otherwise
+print("-- unprojection by number of views, %d frames (channel-last maps, grid parameters, softmax)" % frames)
+for views in (2, 3, 4, 16):
+    c = synth.device_volumetric_case(5, frames, views, dev)
+    f_v = c["features"].view(frames * views, 32, 96, 96).contiguous(memory_format=torch.channels_last).view(frames, views, 32, 96, 96)
+    p_v = c["proj"]
+    line = "  %2d views:" % views
+    for name, mask in (("default", 0), ("tile kernel", 1)):
+        lib.mvx_set_kernel_selection(mask)
+        line += "  %s %.3f ms" % (name, timeit(lambda: op.unproject_heatmaps(f_v, p_v, gcoord, "softmax")))
+    lib.mvx_set_kernel_selection(0)
+    print(line)
+    del c, f_v, p_v
