@@ -56,6 +56,7 @@ def algebraic_head():
     net = AlgebraicTriangulationNet.__new__(AlgebraicTriangulationNet)
     torch.nn.Module.__init__(net)
     net.use_confidences, net.heatmap_softmax, net.heatmap_multiplier = True, True, 100.0
+    net.reuse_outputs, net._arena = False, {}
     return net
 
 
@@ -702,6 +703,36 @@ def latency_p50(dev, n_views=16, launches=1000):
         ts.append(time.perf_counter() - t0)
     out = {"batch1_16view_latency_p50_us": float(np.percentile(ts, 50) * 1e6),
            "batch1_16view_latency_p99_us": float(np.percentile(ts, 99) * 1e6)}
+    # the class path with its per-shape output arena switched on (a frame loop that is done with one frame's results
+    # before it asks for the next: nothing is allocated per call)
+    net.reuse_outputs = True
+    for _ in range(50):
+        net.triangulate_from_heatmaps(hm, conf, proj, (384, 384))
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(launches):
+        t0 = time.perf_counter()
+        net.triangulate_from_heatmaps(hm, conf, proj, (384, 384))
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    out["batch1_16view_reuse_outputs_latency_p50_us"] = float(np.percentile(ts, 50) * 1e6)
+    out["batch1_16view_reuse_outputs_latency_p99_us"] = float(np.percentile(ts, 99) * 1e6)
+    # one frame of the real-time loop end to end (the reference's real_pipeline_trt.py:336-399 without the backbone and
+    # the socket): soft-argmax + DLT, then the pose into the window, Savitzky-Golay filter, joint order / axis map /
+    # scale, the two message frames copied to the host and turned into the wire dictionaries
+    from poseestimation_amd.realtime import RealtimeTail
+    tail = RealtimeTail()
+    for _ in range(50):
+        tail.push(net.triangulate_from_heatmaps(hm, conf, proj, (384, 384))[0][0])
+    ts = []
+    for _ in range(launches):
+        t0 = time.perf_counter()
+        msgs = tail.push(net.triangulate_from_heatmaps(hm, conf, proj, (384, 384))[0][0])
+        ts.append(time.perf_counter() - t0)
+    assert len(msgs) == 2 and len(msgs[0]) == 17
+    out["frame_loop_16view_latency_p50_us"] = float(np.percentile(ts, 50) * 1e6)
+    out["frame_loop_16view_latency_p99_us"] = float(np.percentile(ts, 99) * 1e6)
+    net.reuse_outputs = False
     # the same frame through the bare C entry point with caller-owned outputs (what a serving loop would do)
     lib = _cabi.load()
     b, v, j, h, w = hm.shape

@@ -123,3 +123,8 @@ def ptr(t):
 
 def stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def raw_stream(device_index):
+    """Handle of torch's current stream on device `device_index` as a plain integer (no Stream object built)."""
+    return torch._C._cuda_getCurrentRawStream(device_index)

@@ -206,6 +206,12 @@ class AlgebraicTriangulationNet(nn.Module):
         self.backbone = backbone if backbone is not None else _reference_backbone(config.model.backbone, device)
         self.heatmap_softmax = config.model.heatmap_softmax
         self.heatmap_multiplier = config.model.heatmap_multiplier
+        # Not in the reference.  False: every call returns freshly allocated tensors, as the reference does.  True
+        # (for frame loops that finish with one frame's results before asking for the next, as real_pipeline_trt.py
+        # does): the output tensors of a call are kept per input shape and handed out again by the next call of that
+        # shape, which then allocates nothing -- results of an earlier call are overwritten by a later one.
+        self.reuse_outputs = False
+        self._arena = {}
 
     def triangulate_from_heatmaps(self, heatmaps, alg_confidences, proj_matricies, image_shape):
         """Everything after the backbone: soft-argmax (multiplier folded in), confidence normalisation,
@@ -213,7 +219,8 @@ class AlgebraicTriangulationNet(nn.Module):
 
         heatmaps (B, V, J, h, w) raw backbone output; alg_confidences (B, V, J); proj_matricies (B, V, 3, 4)
         for image pixels; image_shape (H, W).  Returns (keypoints_3d (B, J, 3), keypoints_2d (B, V, J, 2) in
-        image pixels, normalised heatmaps (B, V, J, h, w), confidences (B, V, J))."""
+        image pixels, normalised heatmaps (B, V, J, h, w), confidences (B, V, J)); see `reuse_outputs` for who owns
+        them."""
         _cabi.forward_only("AlgebraicTriangulationNet.triangulate_from_heatmaps", heatmaps, alg_confidences,
                            proj_matricies)
         hm = _cabi.device_f32(heatmaps, "heatmaps")
@@ -223,24 +230,36 @@ class AlgebraicTriangulationNet(nn.Module):
         if tuple(proj.shape) != (b, v, 3, 4):
             raise ValueError("proj_matricies must have shape %s, got %s" % ((b, v, 3, 4), tuple(proj.shape)))
         _cabi.same_device(hm, "heatmaps", alg_confidences=conf, proj_matricies=proj)
-        hm_norm = torch.empty_like(hm)
-        # one allocation for the small outputs: heatmap-pixel keypoints, image-pixel keypoints, confidences, joints
-        n2, n1, n3 = b * v * j * 2, b * v * j, b * j * 3
-        small = torch.empty(2 * n2 + n1 + n3, dtype=torch.float32, device=hm.device)
-        _, kp_img, conf_norm, kp3d = small.split((n2, n2, n1, n3))
-        kp_img, conf_norm, kp3d = kp_img.view(b, v, j, 2), conf_norm.view(b, v, j), kp3d.view(b, j, 3)
-        base = small.data_ptr()
-        args = (_cabi.ptr(hm), _cabi.ptr(conf), _cabi.ptr(proj), b, v, j, h, w, float(self.heatmap_multiplier),
-                int(bool(self.heatmap_softmax)), float(image_shape[1] / w), float(image_shape[0] / h),
-                _cabi.ptr(hm_norm), base + 4 * n2, base + 8 * n2, base + 8 * n2 + 4 * n1, base)
+        index = hm.device.index
+        key = (b, v, j, h, w, index)
+        slot = self._arena.get(key) if self.reuse_outputs else None
+        if slot is None:
+            hm_norm = torch.empty_like(hm)
+            # one allocation for the small outputs: heatmap-pixel keypoints, image-pixel keypoints, confidences, joints
+            n2, n1, n3 = b * v * j * 2, b * v * j, b * j * 3
+            small = torch.empty(2 * n2 + n1 + n3, dtype=torch.float32, device=hm.device)
+            _, kp_img, conf_norm, kp3d = small.split((n2, n2, n1, n3))
+            base = small.data_ptr()
+            # results, then the output pointers in the order mvx_algebraic_forward takes them
+            slot = ((kp3d.view(b, j, 3), kp_img.view(b, v, j, 2), hm_norm, conf_norm.view(b, v, j)),
+                    (hm_norm.data_ptr(), base + 4 * n2, base + 8 * n2, base + 8 * n2 + 4 * n1, base), small)
+            if self.reuse_outputs:
+                self._arena[key] = slot
+        results, out_ptrs, _ = slot
         lib = _cabi.load()
-        if hm.device.index == torch.cuda.current_device():   # the common case: no device switch around the call
-            st = lib.mvx_algebraic_forward(*args, _cabi.stream(hm.device))
+        # (device pointers travel as plain integers: the argument types declared for the entry point convert them)
+        if index == torch.cuda.current_device():   # the common case: no device switch around the call
+            st = lib.mvx_algebraic_forward(hm.data_ptr(), conf.data_ptr(), proj.data_ptr(), b, v, j, h, w,
+                                           self.heatmap_multiplier, 1 if self.heatmap_softmax else 0, image_shape[1] / w,
+                                           image_shape[0] / h, *out_ptrs, _cabi.raw_stream(index))
         else:
             with torch.cuda.device(hm.device):
-                st = lib.mvx_algebraic_forward(*args, _cabi.stream(hm.device))
-        _cabi.check(st, "mvx_algebraic_forward")
-        return kp3d, kp_img, hm_norm, conf_norm
+                st = lib.mvx_algebraic_forward(hm.data_ptr(), conf.data_ptr(), proj.data_ptr(), b, v, j, h, w,
+                                               self.heatmap_multiplier, 1 if self.heatmap_softmax else 0,
+                                               image_shape[1] / w, image_shape[0] / h, *out_ptrs, _cabi.raw_stream(index))
+        if st != _cabi.MVX_OK:
+            _cabi.check(st, "mvx_algebraic_forward")
+        return results
 
     def forward(self, images, proj_matricies, batch):
         device = images.device

@@ -5,6 +5,7 @@ launch stores the new pose, smooths the window and maps both frames of a message
 them to the host.  Sockets and queues (send_msg.py) are not part of
 this module: `encode` returns the bytes the reference hands to its socket.
 """
+import contextlib
 import json
 
 import numpy as np
@@ -17,6 +18,9 @@ from poseestimation_amd.savgol_filer import fit_window, hat_matrix
 UNITY_JOINTS = ('Hip', 'RightHip', 'RightKnee', 'RightAnkle', 'LeftHip', 'LeftKnee', 'LeftAnkle', 'Spine', 'Thorax',
                 'Neck', 'Head', 'LeftShoulder', 'LeftElbow', 'LeftWrist', 'RightShoulder', 'RightElbow', 'RightWrist')
 POINT_CHANGE = (6, 2, 1, 0, 3, 4, 5, 7, 8, 16, 9, 13, 14, 15, 12, 11, 10)
+
+
+_NO_SWITCH = contextlib.nullcontext()
 
 
 def unity_points(points, scale=1.0, order=POINT_CHANGE):
@@ -53,6 +57,9 @@ class RealtimeTail:
         self._ring = None          # (window_frames, J, 3) on the device: slot frames_seen % window_frames is the oldest
         self._order_t = None
         self._out = None
+        self._host = None
+        self._host_np = None
+        self._ptrs = None
         self._hat = None
         self._window = 1
 
@@ -62,8 +69,12 @@ class RealtimeTail:
         self._ring = torch.zeros((self.window_frames, n_joints, 3), dtype=torch.float32, device=dev)
         self._order_t = torch.tensor(self.order, dtype=torch.int32, device=dev)
         self._out = torch.empty((2, n_joints, 3), dtype=torch.float32, device=dev)
+        # the two message frames land in page-locked host memory: one asynchronous copy and one stream wait per frame
+        self._host = torch.empty((2, n_joints, 3), dtype=torch.float32, pin_memory=True)
+        self._host_np = self._host.numpy()
         self._window, order = fit_window(self.slide_window_size, self.window_frames)
         self._hat = hat_matrix(self._window, order, dev)
+        self._ptrs = (self._ring.data_ptr(), self._hat.data_ptr(), self._order_t.data_ptr(), self._out.data_ptr())
 
     def push(self, keypoints_3d):
         """One launch (the pose enters the device ring, the window is smoothed, joints and axes are mapped and
@@ -71,7 +82,8 @@ class RealtimeTail:
         pose = _cabi.device_f32(keypoints_3d, "keypoints_3d").reshape(-1, 3)
         if self._ring is None:
             self._setup(pose)
-        _cabi.same_device(self._ring, "the pose ring", keypoints_3d=pose)
+        if pose.device != self._ring.device:
+            _cabi.same_device(self._ring, "the pose ring", keypoints_3d=pose)
         n_joints = pose.shape[0]
         if n_joints != self._ring.shape[1]:
             raise ValueError("pose has %d joints, the first frame had %d" % (n_joints, self._ring.shape[1]))
@@ -80,13 +92,18 @@ class RealtimeTail:
         # the reference filters once its frame counter (= poses stored, the new one included) exceeds the window size
         filtered = self.frames_seen > self.slide_window_size and self.frames_seen >= self.window_frames
         first = self.scale is None
-        with torch.cuda.device(pose.device):
-            st = _cabi.load().mvx_realtime_tail(
-                _cabi.ptr(self._ring), _cabi.ptr(pose), slot, self.window_frames, n_joints, _cabi.ptr(self._hat),
-                self._window, _cabi.ptr(self._order_t), 1.0 if first else float(self.scale), int(filtered),
-                _cabi.ptr(self._out), _cabi.stream(pose.device))
-        _cabi.check(st, "mvx_realtime_tail")
-        host = self._out.cpu().numpy() if filtered else self._out[:1].cpu().numpy()
+        ring, hat, order, out = self._ptrs
+        index = pose.device.index
+        with (_NO_SWITCH if index == torch.cuda.current_device() else torch.cuda.device(pose.device)):
+            st = _cabi.load().mvx_realtime_tail(ring, pose.data_ptr(), slot, self.window_frames, n_joints, hat, self._window,
+                                                order, 1.0 if first else float(self.scale), int(filtered), out,
+                                                _cabi.raw_stream(index))
+            if st != _cabi.MVX_OK:
+                _cabi.check(st, "mvx_realtime_tail")
+            n_out = 2 if filtered else 1
+            self._host[:n_out].copy_(self._out[:n_out], non_blocking=True)
+            torch.cuda.current_stream(pose.device).synchronize()
+        host = self._host_np[:n_out]
         if first:
             # bone between wire joints 2 and 3 of the first frame; numpy float32 arithmetic as in the pipeline
             self.scale = np.float32(self.unity_len) / np.float32(np.linalg.norm(host[0][2] - host[0][3]))
@@ -95,8 +112,8 @@ class RealtimeTail:
 
     def message(self, wire_points):
         """(J, 3) array already in wire order and scale -> {joint name: [x, y, z]} of Python floats."""
-        return {self.names[j]: [float(wire_points[j][0]), float(wire_points[j][1]), float(wire_points[j][2])]
-                for j in range(len(self.names))}
+        points = np.asarray(wire_points)[:len(self.names)].tolist()   # float32 -> Python float, exactly
+        return dict(zip(self.names, points))
 
     @staticmethod
     def encode(message):

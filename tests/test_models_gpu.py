@@ -62,6 +62,40 @@ def test_algebraic_forward_matches_reference_forward():
     assert np.array_equal(c.cpu().numpy(), oconf)
 
 
+def test_algebraic_reuse_outputs_allocates_nothing_and_changes_no_bit():
+    """`reuse_outputs` (not in the reference): the outputs of a shape are allocated once and handed out again; the
+    numbers are the default path's, bit for bit, the 6-tuple of forward stays, and a second shape gets its own set."""
+    case = synth.algebraic_case(78, 1, 16)
+    other = synth.algebraic_case(79, 2, 4)
+    cfg = ns(model=ns(use_confidences=True, heatmap_softmax=True, heatmap_multiplier=100.0,
+                      backbone=ns(alg_confidences=None, vol_confidences=None)))
+    net = AlgebraicTriangulationNet(cfg, device=DEV, backbone=torch.nn.Identity())
+    args = (t(case["heatmaps"]), t(case["confidences"]), t(case["proj"]), (384, 384))
+    args_other = (t(other["heatmaps"]), t(other["confidences"]), t(other["proj"]), (384, 384))
+    fresh = [x.clone() for x in net.triangulate_from_heatmaps(*args)]
+    fresh_other = [x.clone() for x in net.triangulate_from_heatmaps(*args_other)]
+    net.reuse_outputs = True
+    first = net.triangulate_from_heatmaps(*args)
+    assert all(torch.equal(a, b) for a, b in zip(first, fresh))
+    ptrs = [x.data_ptr() for x in first]
+    got_other = net.triangulate_from_heatmaps(*args_other)
+    assert all(torch.equal(a, b) for a, b in zip(got_other, fresh_other))
+    torch.cuda.synchronize()
+    allocated = torch.cuda.memory_allocated()
+    for _ in range(5):
+        again = net.triangulate_from_heatmaps(*args)
+        assert [x.data_ptr() for x in again] == ptrs
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() == allocated
+    assert all(torch.equal(a, b) for a, b in zip(again, fresh))
+    # a different frame through the same arena overwrites the earlier result (the documented trade)
+    shifted = args[0].roll(3, dims=-1).contiguous()
+    moved = net.triangulate_from_heatmaps(shifted, *args[1:])
+    assert moved[0].data_ptr() == ptrs[0] and not torch.equal(moved[0], fresh[0])
+    o3d, _, _, _ = orc.algebraic_forward(shifted.cpu().numpy(), case["confidences"], case["proj"])
+    assert np.abs(moved[0].cpu().numpy() - o3d).max() <= 1e-3
+
+
 def test_algebraic_without_confidences_uses_ones():
     case = synth.algebraic_case(77, 1, 4)
     hm, proj = case["heatmaps"], case["proj"]

@@ -37,7 +37,7 @@ struct Case {
 
 template <class F>
 static float time_ms(F&& launch, int reps = 15) {
-    for (int i = 0; i < 2; ++i) launch();
+    for (int i = 0; i < 30; ++i) launch();  // the clocks ramp up over the first launches after an idle spell
     if (hipDeviceSynchronize() != hipSuccess) {
         printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
         exit(1);
