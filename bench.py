@@ -539,14 +539,27 @@ def cpu_baseline_ransac(sample_frames):
                       "scipy least_squares(huber) refinement; one pass" % sample_frames}
 
 
-def run_ransac(args, dev, rank, world, frames=4096):
-    from poseestimation_amd.mvn.models.triangulation import all_view_pairs
+def run_ransac(args, dev, rank, world, frames=4096, view_pairs="sampled"):
+    """view_pairs "sampled": the reference's hypotheses -- per (frame, joint) ten pairs from Python's `random`
+    (mvn/models/triangulation.py:96-97), drawn for the next step on a host thread while the GPU runs the current one;
+    "all": every pair, no host work (not what the reference does)."""
+    import random
+
+    from poseestimation_amd.mvn.models.triangulation import ViewPairPrefetcher, all_view_pairs
     case = synth.device_algebraic_case(1234 + 1 + rank, frames, 4, dev)
     hm, proj = case["heatmaps"], case["proj"]
     b, v, j, h, w = hm.shape
     lib = _cabi.load()
-    pairs = torch.from_numpy(np.ascontiguousarray(all_view_pairs(b * j, v))).to(dev)
-    n_iters = pairs.shape[1]
+    prefetch = None
+    if view_pairs == "sampled":
+        random.seed(1234 + rank)
+        prefetch = ViewPairPrefetcher(b * j, v, 10, dev)
+        prefetch.start()
+        n_iters = 10
+        pairs = None
+    else:
+        pairs = torch.from_numpy(np.ascontiguousarray(all_view_pairs(b * j, v))).to(dev)
+        n_iters = pairs.shape[1]
     kp = torch.empty((b, v, j, 2), dtype=torch.int64, device=dev)
     kp_f64 = torch.empty((b, v, j, 2), dtype=torch.float64, device=dev)
     out = torch.empty((b, j, 3), dtype=torch.float64, device=dev)
@@ -558,22 +571,26 @@ def run_ransac(args, dev, rank, world, frames=4096):
     def launch_argmax():
         return lib.mvx_heatmap_argmax(_cabi.ptr(hm), b * v * j, h, w, 384.0 / w, 384.0 / h, _cabi.ptr(kp), st)
 
-    def launch_ransac(kp3d):
+    def launch_ransac(kp3d, step_pairs):
         kp_f64.copy_(kp)
-        rc = lib.mvx_triangulate_ransac(_cabi.ptr(proj), _cabi.ptr(kp_f64), _cabi.ptr(pairs), b, v, j, n_iters, 15.0, 1,
+        rc = lib.mvx_triangulate_ransac(_cabi.ptr(proj), _cabi.ptr(kp_f64), _cabi.ptr(step_pairs), b, v, j, n_iters, 15.0, 1,
                                         _cabi.ptr(out), _cabi.ptr(masks), st)
         kp3d.copy_(out)
         return rc
 
     def step(timed):
         kp3d = sg.buffer()
+        step_pairs = pairs
+        if prefetch is not None:
+            step_pairs = prefetch.take()   # this step's hypotheses (waits for the host draw if it is the slower side)
+            prefetch.start()               # the next step's are drawn while the GPU works on this one
         if timed:
             with ka:
                 rc = launch_argmax()
             with kr:
-                rc |= launch_ransac(kp3d)
+                rc |= launch_ransac(kp3d, step_pairs)
         else:
-            rc = launch_argmax() | launch_ransac(kp3d)
+            rc = launch_argmax() | launch_ransac(kp3d, step_pairs)
         if rc != 0:
             raise RuntimeError("mvx call failed: %s" % lib.mvx_last_error().decode())
         sg.submit()
@@ -593,9 +610,23 @@ def run_ransac(args, dev, rank, world, frames=4096):
         "heatmap_argmax<9>", {"maps": frames * v * j, "map": [h, w], "heatmap_writeback": False})
     extra = {"ransac_kernel_and_casts_ms": kr.mean_ms(), "max_abs_error_vs_synthetic_truth_mm": float(err),
              "mean_inlier_views": float(torch.bitwise_and(masks.view(-1, 1) >> torch.arange(4, device=dev), 1).sum(1).float().mean())}
-    cfg = {"workload": "ransac: heatmap arg-max + RANSAC (all 6 view pairs) + inlier DLT + Huber refinement, "
-                       "%d frames/GPU x 4 views x 17 joints, 96x96 heatmaps" % frames, "frames_per_gpu": frames,
-           "views": v, "joints": j, "parallelism": "frames sharded over %d GPU(s), all-gather of keypoints" % world}
+    if prefetch is not None:
+        prefetch.take()   # the draw begun by the last step
+        # the host side alone: one draw of a step's pairs, not overlapped with anything
+        t0 = time.perf_counter()
+        prefetch.start()
+        prefetch.take()
+        torch.cuda.synchronize(dev)
+        extra["view_pair_draw_ms_per_step"] = (time.perf_counter() - t0) * 1e3
+        extra["direct_optimization_tolerance_note"] = (
+            "with direct_optimization the refined points are checked against the reference at 2e-2 mm (scipy's "
+            "least_squares stops short of the minimiser; the kernel's cost is never above the reference's), not 1e-3 mm")
+    how = ("10 view pairs per joint sampled as the reference samples them (Python's generator state continued natively, "
+           "drawn one step ahead on a host thread)" if view_pairs == "sampled" else "all 6 view pairs")
+    cfg = {"workload": "ransac: heatmap arg-max + RANSAC (%s) + inlier DLT + Huber refinement, "
+                       "%d frames/GPU x 4 views x 17 joints, 96x96 heatmaps" % (how, frames), "frames_per_gpu": frames,
+           "views": v, "joints": j, "view_pairs": view_pairs,
+           "parallelism": "frames sharded over %d GPU(s), all-gather of keypoints" % world}
     return ms, frames, roof, cfg, extra
 
 
@@ -795,7 +826,12 @@ def run_workload(name, args, dev, rank, world):
     elif name == "volumetric":
         ms, frames, roof, cfg, extra = run_volumetric(args, dev, rank, world, args.frames or 64)
     elif name == "ransac":
-        ms, frames, roof, cfg, extra = run_ransac(args, dev, rank, world, args.frames or 4096)
+        ms, frames, roof, cfg, extra = run_ransac(args, dev, rank, world, args.frames or 4096, "sampled")
+        ms_all, frames_all, _, _, extra_all = run_ransac(with_steps(args, min(args.steps, 10), 2), dev, rank, world,
+                                                         args.frames or 4096, "all")
+        extra["all_view_pairs"] = {"value": frames_all * world / (ms_all * 1e-3), "unit": "frames/s", "ms_per_step": ms_all,
+                                   "ransac_kernel_and_casts_ms": extra_all["ransac_kernel_and_casts_ms"],
+                                   "note": "every pair instead of the reference's ten sampled ones: no host work"}
     elif name == "sharded":
         total = args.frames or 65536
         ms, frames, roof, cfg, extra = run_sharded(args, dev, rank, world, total)

@@ -61,26 +61,92 @@ def draw_view_pairs_python(n_points, n_views, n_iters):
     return pairs
 
 
-def draw_view_pairs(n_points, n_views, n_iters):
+def draw_view_pairs(n_points, n_views, n_iters, out=None):
     """(n_points, n_iters, 2) uint8 view pairs drawn exactly as the reference draws them: for each point in
     order, `n_iters` calls of `sorted(random.sample(views, 2))` on Python's global generator
     (mvn/models/triangulation.py:96-97), so that `random.seed(s)` before a forward gives the reference's
     hypotheses.  (The reference samples from a set, which Python 3.11 no longer accepts; a range of the same
     length consumes the generator identically.)  The draws are made by a native host routine that continues
     the generator's Mersenne Twister state and hands it back, so Python's `random` ends up where the
-    reference's calls would have left it."""
+    reference's calls would have left it.  `out`: a C-contiguous uint8 array of that shape to fill (for instance
+    the numpy view of a page-locked tensor) instead of a new one."""
     if not 2 <= n_views <= 255:
         raise ValueError("view pairs are stored as uint8: 2 to 255 views, got %d" % n_views)
     import ctypes
     version, internal, gauss_next = random.getstate()
     state = np.array(internal[:624], dtype=np.uint32)
     pos = ctypes.c_int32(internal[624])
-    pairs = np.empty((n_points, n_iters, 2), dtype=np.uint8)
+    if out is None:
+        pairs = np.empty((n_points, n_iters, 2), dtype=np.uint8)
+    else:
+        pairs = out
+        if pairs.dtype != np.uint8 or pairs.shape != (n_points, n_iters, 2) or not pairs.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape %s" % ((n_points, n_iters, 2),))
     st = _cabi.load().mvx_draw_view_pairs(state.ctypes.data, ctypes.addressof(pos), int(n_views),
                                           int(n_points) * int(n_iters), pairs.ctypes.data)
     _cabi.check(st, "mvx_draw_view_pairs")
-    random.setstate((version, tuple(int(x) for x in state) + (pos.value,), gauss_next))
+    random.setstate((version, tuple(state.tolist()) + (pos.value,), gauss_next))
     return pairs
+
+
+class ViewPairPrefetcher:
+    """Draws the view pairs of the NEXT batch on a host thread while the GPU works on the current one, and uploads
+    them from page-locked memory (the draw is sequential host work -- about two Mersenne Twister words per index --
+    and the native routine releases the interpreter lock).  The pairs are the ones `draw_view_pairs` gives in the
+    same order of calls, so a loop that seeds `random` and then takes one set of pairs per batch sees the
+    reference's hypotheses; nothing else may use Python's global generator while a draw is under way.
+
+        pf = ViewPairPrefetcher(batch * joints, views, 10, device); pf.start()
+        for batch in batches:
+            pairs = pf.take(); pf.start()        # this batch's pairs (device tensor); begin the next draw
+            ransac_triangulate_batch(proj, keypoints, pairs, ...)
+    """
+
+    def __init__(self, n_points, n_views, n_iters, device):
+        self.shape = (int(n_points), int(n_iters), 2)
+        self.n_views = int(n_views)
+        self.device = torch.device(device)
+        self._host = [torch.empty(self.shape, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        self._dev = [torch.empty(self.shape, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self._uploaded = [None, None]   # event after the last upload from host buffer i
+        self._slot = 0
+        self._thread = None
+        self._error = None
+
+    def _draw(self, slot):
+        try:
+            if self._uploaded[slot] is not None:
+                self._uploaded[slot].synchronize()   # the upload that last read this buffer has finished
+            draw_view_pairs(self.shape[0], self.n_views, self.shape[1], out=self._host[slot].numpy())
+        except BaseException as e:   # handed to the thread that calls take()
+            self._error = e
+
+    def start(self):
+        """Begins drawing the next set of pairs (returns at once)."""
+        if self._thread is not None:
+            raise RuntimeError("a draw is already under way: take() its result first")
+        import threading
+        self._thread = threading.Thread(target=self._draw, args=(self._slot,), daemon=True)
+        self._thread.start()
+
+    def take(self):
+        """Waits for the draw begun by start() and returns its pairs as a uint8 tensor on the device (valid until
+        the take() after next)."""
+        if self._thread is None:
+            raise RuntimeError("start() has not been called")
+        self._thread.join()
+        self._thread = None
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
+        slot = self._slot
+        self._slot ^= 1
+        with torch.cuda.device(self.device):
+            self._dev[slot].copy_(self._host[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._uploaded[slot] = ev
+        return self._dev[slot]
 
 
 def all_view_pairs(n_points, n_views):

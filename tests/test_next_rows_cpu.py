@@ -92,6 +92,16 @@ def test_native_view_pair_draws_continue_pythons_generator(n_views):
     assert (draw_view_pairs(0, n_views, 10).shape, draw_view_pairs(3, n_views, 0).shape) == ((0, 10, 2), (3, 0, 2))
     with pytest.raises(ValueError):
         draw_view_pairs(1, 256, 1)
+    # into a caller's buffer: the same draws; a buffer of another shape or type is refused
+    random.seed(3)
+    want = draw_view_pairs(31, n_views, 10)
+    random.seed(3)
+    buf = np.zeros((31, 10, 2), dtype=np.uint8)
+    assert draw_view_pairs(31, n_views, 10, out=buf) is buf and np.array_equal(buf, want)
+    with pytest.raises(ValueError):
+        draw_view_pairs(31, n_views, 10, out=np.zeros((31, 10, 2), dtype=np.int32))
+    with pytest.raises(ValueError):
+        draw_view_pairs(30, n_views, 10, out=buf)
 
 
 # ---- temporal filter ---------------------------------------------------------------------------------------------

@@ -174,6 +174,37 @@ def test_triangulate_ransac_single_point_api():
         net.triangulate_ransac(proj[0, :1], kp[0, :1, 0])
 
 
+def test_view_pair_prefetcher_gives_the_sequence_of_direct_draws():
+    """ViewPairPrefetcher (pairs of the next batch drawn on a host thread, uploaded from page-locked memory): batch
+    after batch the same pairs as draw_view_pairs called in the same order, Python's generator left where those calls
+    leave it, and the triangulation fed by it equal to the one fed the directly drawn pairs."""
+    from poseestimation_amd.mvn.models.triangulation import ViewPairPrefetcher, draw_view_pairs, ransac_triangulate_batch
+    case = synth.algebraic_case(61, 6, 4)
+    proj = torch.from_numpy(case["proj"]).to("cuda:0")
+    kp = torch.tensor(np.random.default_rng(2).uniform(0, 384, (6, 4, 17, 2)), dtype=torch.float64, device="cuda:0")
+    n_points = 6 * 17
+    random.seed(99)
+    want = [draw_view_pairs(n_points, 4, 10) for _ in range(4)]
+    state_after = random.getstate()
+    random.seed(99)
+    pf = ViewPairPrefetcher(n_points, 4, 10, "cuda:0")
+    pf.start()
+    with pytest.raises(RuntimeError):
+        pf.start()
+    for i in range(4):
+        pairs = pf.take()
+        if i < 3:
+            pf.start()
+        assert pairs.is_cuda and pairs.dtype == torch.uint8
+        got3d, got_mask = ransac_triangulate_batch(proj, kp, pairs, 15.0, False)
+        assert np.array_equal(pairs.cpu().numpy(), want[i]), i
+        ref3d, ref_mask = ransac_triangulate_batch(proj, kp, want[i], 15.0, False)
+        assert torch.equal(got3d, ref3d) and torch.equal(got_mask, ref_mask)
+    assert random.getstate() == state_after
+    with pytest.raises(RuntimeError):
+        pf.take()
+
+
 def test_ransac_many_views_and_all_pairs():
     """Sixteen views with three corrupted ones, every pair as hypothesis: the corrupted views are rejected and the
     points agree with the oracle run on the same pairs."""
