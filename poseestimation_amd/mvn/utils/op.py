@@ -40,6 +40,15 @@ def _grid_of(coord_volumes, n_frames, vshape):
     return grid
 
 
+def _as_input_dtype(like, *results):
+    """float64 inputs give float64 results, as the reference's torch arithmetic does (mvn/utils/op.py:34-35: the
+    float32 index ranges are promoted to the dtype of the heatmaps).  The kernels read float32 (a float64 input is
+    rounded to it first) and accumulate in float64, so such results carry float32 accuracy in a float64 tensor."""
+    if torch.is_tensor(like) and like.dtype == torch.float64:
+        return tuple(r.double() if r is not None else None for r in results)
+    return results
+
+
 def _soft_argmax_2d(heatmaps, softmax, multiplier, return_heatmaps):
     _cabi.forward_only("integrate_tensor_2d", heatmaps)
     hm = _cabi.device_f32(heatmaps, "heatmaps")
@@ -53,7 +62,7 @@ def _soft_argmax_2d(heatmaps, softmax, multiplier, return_heatmaps):
         st = lib.mvx_soft_argmax_2d(_cabi.ptr(hm), n * k, h, w, float(multiplier), int(bool(softmax)),
                                     _cabi.ptr(coords), _cabi.ptr(out), _cabi.stream(hm.device))
     _cabi.check(st, "mvx_soft_argmax_2d")
-    return coords, out
+    return _as_input_dtype(heatmaps, coords, out)
 
 
 def integrate_tensor_2d(heatmaps, softmax=True, *, multiplier=1.0, return_heatmaps=True):
@@ -99,7 +108,7 @@ def _soft_argmax_3d(volumes, coord_volumes, softmax, multiplier, return_volumes)
                                         int(bool(softmax)), _cabi.ptr(coords), _cabi.ptr(out), _cabi.ptr(ws),
                                         ws.numel() * 8, _cabi.stream(vol.device))
     _cabi.check(st, "mvx_soft_argmax_3d")
-    return coords, out
+    return _as_input_dtype(volumes, coords, out)
 
 
 def integrate_tensor_3d(volumes, softmax=True, *, multiplier=1.0, return_volumes=True):
@@ -194,7 +203,7 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
                                    vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(volumes), _cabi.ptr(ws), ws_bytes,
                                    dev_stream)
     _cabi.check(st, what)
-    return volumes
+    return _as_input_dtype(heatmaps, volumes)[0]
 
 
 def gaussian_2d_pdf(coords, means, sigmas, normalize=True):

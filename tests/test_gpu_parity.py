@@ -124,9 +124,13 @@ def test_soft_argmax_2d_edge_cases():
     # non-contiguous and float64 inputs are accepted
     base = torch.randn((2, 3, 96, 192), device=dev(), dtype=torch.float64)
     view = base[..., ::2]
-    c1, _ = op.integrate_tensor_2d(view)
-    c2, _ = op.integrate_tensor_2d(view.contiguous().float())
-    assert torch.equal(c1, c2)
+    c1, h1 = op.integrate_tensor_2d(view)
+    c2, h2 = op.integrate_tensor_2d(view.contiguous().float())
+    # float64 in, float64 out (the reference's type promotion), with the float32 kernels' values
+    assert c1.dtype == torch.float64 and h1.dtype == torch.float64 and c2.dtype == torch.float32
+    assert torch.equal(c1, c2.double()) and torch.equal(h1, h2.double())
+    v64 = torch.randn((1, 2, 8, 8, 8), device=dev(), dtype=torch.float64)
+    assert op.integrate_tensor_3d(v64)[0].dtype == torch.float64 and op.integrate_tensor_3d(v64.float())[0].dtype == torch.float32
     # a NaN from the backbone stays visible on both paths, as with torch's softmax and relu: the map that holds
     # it gets NaN coordinates and (relu) a NaN at that pixel; the other maps are untouched
     for shape in ((2, 3, 96, 96), (2, 3, 40, 36), (2, 3, 13, 11)):     # register kernel, guarded slots, any-shape kernel
