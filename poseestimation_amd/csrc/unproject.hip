@@ -550,6 +550,13 @@ struct BrickShared {
 #ifdef MVX_BRICK_STATS  // development builds only (tools/brick_stats.hip)
 __device__ unsigned brick_stats[4];  // bricks, bricks on the direct path, bricks whose patches do not fit, max rows
 #endif
+#ifdef MVX_BRICK_TRACE  // development builds only (tools/brick_lab.hip): s_memtime at the phase boundaries of every wave
+constexpr int kTraceStamps = 20;
+__device__ unsigned long long* brick_trace;  // [workgroup][wave][kTraceStamps]
+#define MVX_TRACE(i) trace_[i] = __builtin_readcyclecounter()
+#else
+#define MVX_TRACE(i)
+#endif
 
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -639,6 +646,10 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
     const int64_t n = (static_cast<int64_t>(bx * kBrick + lx) * vy + by * kBrick + ly) * vz + bz * kBrick + lz;
     const size_t img_stride = static_cast<size_t>(H) * W * C;
     const float* fb = feat_cl + b * NV * img_stride;
+#ifdef MVX_BRICK_TRACE
+    unsigned long long trace_[kTraceStamps] = {};
+#endif
+    MVX_TRACE(0);
 
     if (tid < NV * 12) sh->cam[tid] = camera_entry(proj + b * NV * 12 + (tid / 12) * 12, tid % 12, sx, sy);
     if (tid == 64) {
@@ -667,6 +678,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
             Z = cp[2];
         }
     };
+    MVX_TRACE(1);  // cameras in LDS (first barrier)
     load_position(lz);
     float4 wt[NV];
     int txb[NV], tyb[NV];
@@ -746,18 +758,25 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
     };
 
     project_pair(0);
+    MVX_TRACE(2);  // position + projection of views 0, 1
     __syncthreads();
+    MVX_TRACE(3);  // second barrier (corners)
     rectangles_pair(0);
     if (fits) {  // harmless if a lane turns out not to fit: the vote below decides who reads
         stage_one(0);
         stage_one(1);
     }
+    MVX_TRACE(4);  // rectangles, copies issued
     if (NV > 2) project_pair(1);  // (the copies are in flight)
+    MVX_TRACE(5);  // projection of views 2, 3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MVX_TRACE(6);  // own copies landed
     __syncthreads();
+    MVX_TRACE(7);  // third barrier
     if (NV > 2) rectangles_pair(1);
     if (!inside) sh->bad = 1;
     __syncthreads();
+    MVX_TRACE(8);  // rectangles of views 2, 3 and fourth barrier
     const bool staged = fits && (sh->bad == 0);
 
     // voxel of lane (lane & ~3), channel (lane & 3) of a quad: where this lane's 16-byte stores start
@@ -870,6 +889,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every lane has read view 0
             stage_one(2);
         }
+        MVX_TRACE(9 + 2 * v);  // barrier ahead of unit v (and the next copy issued)
         constexpr int kLast = NV - 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -925,7 +945,16 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
             // keep the quads in order: hoisting the reads of later quads would need hundreds of registers
             __builtin_amdgcn_sched_barrier(0);
         }
+        MVX_TRACE(10 + 2 * v);  // unit v sampled (the last one: stores issued)
     }
+#ifdef MVX_BRICK_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MVX_TRACE(17);  // stores acknowledged
+    if (lane == 0) {
+        unsigned long long* dst = brick_trace + (static_cast<size_t>(blockIdx.x) * 8 + wave) * kTraceStamps;
+        for (int i = 0; i < kTraceStamps; ++i) dst[i] = trace_[i];
+    }
+#endif
     if (AGG == MVX_AGG_SOFTMAX) {
         // every denominator in [2^-80, 2^100] (a NaN fails both comparisons)
         if (!(chk_d.x + chk_d.y <= 0x1p100f) || !(chk_r.x + chk_r.y <= 0x1p80f)) sh->redo = 1;

@@ -205,6 +205,47 @@ int main(int argc, char** argv) {
         return 0;
     }
 #endif
+#ifdef MVX_BRICK_TRACE
+    {
+        // s_memtime at the phase boundaries of every wave of one launch (after warm-up launches): mean length of each
+        // phase over the waves of bricks that took the staged path, and of a wave's whole life
+        using namespace mvx;
+        const int bricks = (c.S / kBrick) * (c.S / kBrick) * (c.S / kBrick);
+        const size_t n_waves = static_cast<size_t>(c.B) * bricks * 8;
+        unsigned long long* d_trace = nullptr;
+        hipMalloc(&d_trace, n_waves * kTraceStamps * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(mvx::brick_trace), &d_trace, sizeof(d_trace));
+        for (int agg : {MVX_AGG_SOFTMAX, MVX_AGG_SUM}) {
+            for (int i = 0; i < 30; ++i) library(agg, c.vol);
+            hipMemset(d_trace, 0, n_waves * kTraceStamps * 8);
+            library(agg, c.vol);
+            hipDeviceSynchronize();
+            std::vector<unsigned long long> t(n_waves * kTraceStamps);
+            hipMemcpy(t.data(), d_trace, t.size() * 8, hipMemcpyDeviceToHost);
+            const char* names[17] = {"cameras -> LDS, barrier 1", "position + projection 0,1", "barrier 2 (corners)",
+                                     "rectangles 0,1 + copies issued", "projection 2,3", "wait for own copies", "barrier 3",
+                                     "rectangles 2,3 + barrier 4", "(unit 0 has no barrier)", "unit 0", "barrier + copy 2 issued",
+                                     "unit 1", "wait + barrier + copy 3 issued", "unit 2", "wait + barrier", "unit 3 (+ stores issued)",
+                                     "stores acknowledged"};
+            double sum[17] = {}, life = 0;
+            size_t n = 0;
+            unsigned long long first = ~0ull, last = 0;
+            for (size_t w = 0; w < n_waves; ++w) {
+                const unsigned long long* s = &t[w * kTraceStamps];
+                if (s[17] == 0) continue;  // direct path (returned before the last stamp)
+                for (int i = 0; i < 17; ++i) sum[i] += static_cast<double>(s[i + 1] - s[i]);
+                life += static_cast<double>(s[17] - s[0]);
+                first = std::min(first, s[0]);
+                last = std::max(last, s[17]);
+                ++n;
+            }
+            printf("aggregation %d: %zu of %zu waves on the staged path; kernel span %.0f ticks; mean life of a wave %.0f ticks\n", agg, n,
+                   n_waves, static_cast<double>(last - first), life / n);
+            for (int i = 0; i < 17; ++i) printf("    %-34s %8.0f ticks  %5.1f %%\n", names[i], sum[i] / n, 100.0 * sum[i] / life);
+        }
+        return 0;
+    }
+#endif
     const bool with_stream = argc > 2 && std::string(argv[2]) == "with-stream";
     for (int agg : {MVX_AGG_SOFTMAX, MVX_AGG_SUM, MVX_AGG_MAX}) {  // no confidences in this harness
         printf("aggregation %d: brick kernel, four units of one view (the library's)\n", agg);
