@@ -395,6 +395,8 @@ __global__ __launch_bounds__(kThreads) void unproject_generic(const float* __res
 // C = 32, TILE voxels per workgroup (n_vox % TILE == 0), V <= kTileMaxViews.
 constexpr int kTile = 128;
 constexpr int kTileMaxViews = 16;
+constexpr int kTileViewChunk = 4;  // views whose tap tables are in LDS at a time (more would cost residency: 16 views
+                                   // of tables are 40 KB, two workgroups per CU)
 
 // FOUR: exactly four views, unrolled, with the view softmax evaluated exactly (max, then exp2); otherwise any
 // V <= kTileMaxViews with the online form.
@@ -408,9 +410,10 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
     constexpr int C = 32;
     extern __shared__ __align__(16) unsigned char smem[];
     float* out_t = reinterpret_cast<float*>(smem);                                       // [32][kTile], swizzled
-    float4* wts = reinterpret_cast<float4*>(smem + C * kTile * sizeof(float));           // [V][kTile]
-    unsigned* pix = reinterpret_cast<unsigned*>(wts + static_cast<size_t>(V) * kTile);   // [V][kTile]
-    double* cam = reinterpret_cast<double*>(pix + static_cast<size_t>(V) * kTile);       // [V][12]
+    const int Vc = V < kTileViewChunk ? V : kTileViewChunk;                               // views per chunk of tables
+    float4* wts = reinterpret_cast<float4*>(smem + C * kTile * sizeof(float));           // [Vc][kTile]
+    unsigned* pix = reinterpret_cast<unsigned*>(wts + static_cast<size_t>(Vc) * kTile);  // [Vc][kTile]
+    double* cam = reinterpret_cast<double*>(pix + static_cast<size_t>(Vc) * kTile);      // [V][12]
 
     const int tid = threadIdx.x;
     const unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -418,19 +421,22 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
     const int64_t n0 = static_cast<int64_t>(work % tiles_per_frame) * kTile;
     const size_t img_stride = static_cast<size_t>(H) * W * C;
 
-    // phase A: cameras to float64, then the taps of every (view, voxel) of the tile
+    // phase A: cameras to float64, then the taps of every (view, voxel) of the tile, up to kTileViewChunk views at
+    // a time
     if (tid < V * 12) cam[tid] = camera_entry(proj + b * V * 12 + (tid / 12) * 12, tid % 12, sx, sy);
     __syncthreads();
-    {
+    double X, Y, Z;
+    voxel_position(coord, b, n_vox, n0 + (tid & (kTile - 1)), X, Y, Z);
+    auto project_chunk = [&](int v0) {
         const int t = tid & (kTile - 1);
-        double X, Y, Z;
-        voxel_position(coord, b, n_vox, n0 + t, X, Y, Z);
-        for (int v = tid / kTile; v < V; v += kThreads / kTile) {
+        const int v_end = v0 + Vc < V ? v0 + Vc : V;
+        for (int v = v0 + tid / kTile; v < v_end; v += kThreads / kTile) {
             const Tap tap = project_tap(cam + v * 12, X, Y, Z, H, W, AGG == MVX_AGG_SOFTMAX ? kLog2e : 1.0f);
-            wts[v * kTile + t] = make_float4(tap.w00, tap.w01, tap.w10, tap.w11);
-            pix[v * kTile + t] = tap.pixel;
+            wts[(v - v0) * kTile + t] = make_float4(tap.w00, tap.w01, tap.w10, tap.w11);
+            pix[(v - v0) * kTile + t] = tap.pixel;
         }
-    }
+    };
+    project_chunk(0);
     __syncthreads();
 
     // phase B: 8 lanes per voxel, 4 channels per lane
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
                 out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = r;
             }
         }
-    } else {
+    } else if (V <= kTileViewChunk) {
 #pragma unroll 2
         for (int step = 0; step < kTile / 32; ++step) {
             const int t = step * 32 + (tid >> 3);
@@ -496,6 +502,51 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = agg.result(k);
+        }
+    } else {
+        // more views than one chunk of tables holds: the aggregates of a lane's four voxels stay in registers from
+        // one chunk to the next
+        Aggregator<AGG> agg[kTile / 32];
+#pragma unroll
+        for (int step = 0; step < kTile / 32; ++step) agg[step].init();
+        for (int v0 = 0; v0 < V; v0 += kTileViewChunk) {
+            if (v0 > 0) {
+                __syncthreads();  // every lane has read the tables of the chunk before
+                project_chunk(v0);
+                __syncthreads();
+            }
+            const int nv = V - v0 < kTileViewChunk ? V - v0 : kTileViewChunk;
+#pragma unroll
+            for (int step = 0; step < kTile / 32; ++step) {
+                const int t = step * 32 + (tid >> 3);
+                for (int vv = 0; vv < nv; ++vv) {
+                    const int v = v0 + vv;
+                    const float4 w4 = wts[vv * kTile + t];
+                    Tap tap;
+                    tap.w00 = w4.x;
+                    tap.w01 = w4.y;
+                    tap.w10 = w4.z;
+                    tap.w11 = w4.w;
+                    tap.pixel = pix[vv * kTile + t];
+                    float val[4], conf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    sample4(fb + v * img_stride, tap, W, C, q, val);
+                    if (AGG == MVX_AGG_CONF) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(vconf + (b * V + v) * C + q * 4);
+                        conf[0] = c4.x;
+                        conf[1] = c4.y;
+                        conf[2] = c4.z;
+                        conf[3] = c4.w;
+                    }
+                    agg[step].add(val, conf);
+                }
+            }
+        }
+#pragma unroll
+        for (int step = 0; step < kTile / 32; ++step) {
+            const int t = step * 32 + (tid >> 3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                out_t[(q * 4 + k) * kTile + ((((t >> 2) ^ q) << 2) | (t & 3))] = agg[step].result(k);
         }
     }
     __syncthreads();
@@ -1070,7 +1121,8 @@ int unproject_any_layout(const char* name, bool channels_last, const float* feat
                          aligned16(volumes) &&
                          (aggregation != MVX_AGG_CONF || aligned16(vol_conf)) &&
                          !(kernel_selection() & MVX_SELECT_NO_UNPROJECT_BRICKS);
-    const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V) * kTile * 20 + static_cast<size_t>(V) * 12 * 8;
+    const size_t smem = static_cast<size_t>(32) * kTile * 4 + static_cast<size_t>(V < kTileViewChunk ? V : kTileViewChunk) * kTile * 20 +
+                        static_cast<size_t>(V) * 12 * 8;
     const double sx = static_cast<double>(w - 1) / static_cast<double>(h);  // ix = x / H * (W - 1)
     const double sy = static_cast<double>(h - 1) / static_cast<double>(w);  // iy = y / W * (H - 1)
 

@@ -312,7 +312,7 @@ def unproject_c_abi(feats, proj, coord, vconf, method, misalign_output=False):
     return out.view(b, c, *vs)
 
 
-@pytest.mark.parametrize("side,views", [(2500.0, 4), (2500.0, 3), (9000.0, 4), (30000.0, 2)])
+@pytest.mark.parametrize("side,views", [(2500.0, 4), (2500.0, 3), (9000.0, 4), (30000.0, 2), (2500.0, 8), (2500.0, 16), (9000.0, 6)])
 def test_unproject_kernel_paths_agree(side, views):
     """The tile kernel (C = 32, voxels % 128 == 0) and the generic kernel on the same maps.  A 9 m cuboid has
     tiles with voxels outside every map; at 30 m whole tiles see no view at all."""
