@@ -633,28 +633,43 @@ __device__ __forceinline__ Taps4 patch_taps(unsigned a0, unsigned a1, int q) {
 }
 
 // 4 x 4 transpose across the four lanes of a quad: lane i holds a[0..3] on entry and (lane 0's a[i], lane 1's a[i],
-// lane 2's a[i], lane 3's a[i]) on exit.  Two butterfly stages (lane ^ 1, then lane ^ 2), each a DPP quad
-// permutation and a select per register.
-__device__ __forceinline__ void quad_transpose(float (&a)[4], int lane) {
-    const bool odd = lane & 1, upper = lane & 2;
-    const float s0 = odd ? a[0] : a[1], s1 = odd ? a[2] : a[3];  // what the partner (lane ^ 1) needs
-    const float r0 = dpp_mov<0xB1>(s0), r1 = dpp_mov<0xB1>(s1);
-    if (odd) {
-        a[0] = r0;
-        a[2] = r1;
-    } else {
-        a[1] = r0;
-        a[3] = r1;
-    }
-    const float t0 = upper ? a[0] : a[2], t1 = upper ? a[1] : a[3];  // what the partner (lane ^ 2) needs
-    const float u0 = dpp_mov<0x4E>(t0), u1 = dpp_mov<0x4E>(t1);
-    if (upper) {
-        a[0] = u0;
-        a[1] = u1;
-    } else {
-        a[2] = u0;
-        a[3] = u1;
-    }
+// lane 2's a[i], lane 3's a[i]) on exit.  Two butterfly stages (lane ^ 1, then lane ^ 2), each four selects that take
+// one operand through a DPP quad permutation (v_cndmask_b32_dpp: the select and the cross-lane move are one
+// instruction, eight in all; written as separate selects and moves the compiler needs about 45, recomputing the
+// lane-parity masks for every quad of channels).  Stage 1: an even lane takes its partner's a[0], a[2] as its
+// a[1], a[3], an odd lane its partner's a[1], a[3] as its a[0], a[2]; stage 2 likewise on pairs of registers between
+// the lower and the upper two lanes.  The lane masks are wave-uniform constants handed in through SGPR pairs.
+// (s_nop: a VGPR written by the VALU needs two wait states before a DPP operand reads it, which the assembler does
+// not insert inside an asm block.)
+__device__ __forceinline__ void quad_transpose(float (&a)[4], int /*lane*/) {
+    float n0, n1, n2, n3, m0, m1, m2, m3;
+    const unsigned long long odd = 0xaaaaaaaaaaaaaaaaull, even = 0x5555555555555555ull;
+    const unsigned long long upper = 0xccccccccccccccccull, lower = 0x3333333333333333ull;
+    asm volatile(
+        "s_nop 1\n\t"
+        "s_mov_b64 vcc, %[odd]\n\t"
+        "v_cndmask_b32_dpp %[n1], %[a0], %[a1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[n3], %[a2], %[a3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %[even]\n\t"
+        "v_cndmask_b32_dpp %[n0], %[a1], %[a0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[n2], %[a3], %[a2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %[upper]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_dpp %[m2], %[n0], %[n2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[m3], %[n1], %[n3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %[lower]\n\t"
+        "v_cndmask_b32_dpp %[m0], %[n2], %[n0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[m1], %[n3], %[n1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2),
+          [m3] "=&v"(m3)
+        : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [odd] "s"(odd), [even] "s"(even), [upper] "s"(upper),
+          [lower] "s"(lower)
+        : "vcc");
+    a[0] = m0;
+    a[1] = m1;
+    a[2] = m2;
+    a[3] = m3;
 }
 
 template <int AGG, bool GRID, int NV>
