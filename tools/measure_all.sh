@@ -17,7 +17,9 @@ run volumetric --workload volumetric
 run ransac --workload ransac
 MVX_BENCH_REHEARSAL=1 run rehearsal_2ranks_one_gpu --gpus 2 --steps 5
 cd /tmp && export TMPDIR=/tmp
+# (20 warm-up steps: the clocks ramp up over the first ~15 launches after an idle spell, and the per-kernel average of
+# a profile that starts cold sits well above the steady state the bench line reports)
 for W in algebraic volumetric ransac; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$W" -- python3 "$R/bench.py" --workload $W --steps 10 --no-cpu-baseline --no-extra > "$OUT/prof_$W.log" 2>&1 || { echo "rocprof $W failed"; tail -5 "$OUT/prof_$W.log"; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$W" -- python3 "$R/bench.py" --workload $W --steps 30 --warmup 20 --no-cpu-baseline --no-extra > "$OUT/prof_$W.log" 2>&1 || { echo "rocprof $W failed"; tail -5 "$OUT/prof_$W.log"; exit 1; }
   echo "rocprof $W ok"
 done
