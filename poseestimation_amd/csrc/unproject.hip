@@ -87,8 +87,8 @@ __device__ __forceinline__ void voxel_position(const VoxelSource& src, int64_t b
 // iy = y/W * (H - 1).  Here the camera Pd is float64 with rows 0 and 1 already multiplied by (W-1)/H and
 // (H-1)/W, so ix = u'/z, iy = v'/z; the position is evaluated in float64 and only the interpolation weights
 // are rounded to float32 (the reference's float32 position carries about 1e-5 px of rounding noise, which the
-// feature gradient would multiply).  1/z is v_rcp_f32 refined by two Newton steps in float64 (relative error
-// below 1e-15) instead of a float64 division.  A voxel with z <= 0 gets all-zero weights; `wscale`
+// feature gradient would multiply).  1/z is v_rcp_f32 (1 ulp of float32) refined by one Newton step in float64
+// (relative error below 1e-14: under 1e-12 pixels) instead of a float64 division.  A voxel with z <= 0 gets all-zero weights; `wscale`
 // multiplies the weights (log2 e for the softmax aggregation, which works in base 2).
 struct TapXY {
     float w00, w01, w10, w11;  // as in Tap
@@ -105,7 +105,6 @@ __device__ __forceinline__ TapXY project_tap_xy(const double* __restrict__ Pd, d
     const bool behind = z0 <= 0.0;
     const double z = (z0 == 0.0) ? 1.0 : z0;
     double rz = static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(z)));
-    rz = fma(rz, fma(-z, rz, 1.0), rz);
     rz = fma(rz, fma(-z, rz, 1.0), rz);
     const double ixd = u * rz, iyd = v * rz;
     const double x0d = floor(ixd), y0d = floor(iyd);
@@ -805,20 +804,24 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
             }
         }
     };
-    // starts the copy of the patch of view v into buffer v & 1: rows of 16 pixels, half a row per wave-instruction
+    // starts the copy of the patch of view v into buffer v & 1: rows of 16 pixels, half a row (8 pixels x 128 bytes)
+    // per wave-instruction, row py by wave 2 (py & 3) + half.  The 16-byte channel quad q of a pixel in patch row py
+    // sits at position q ^ (py & 7) of the pixel's 128 bytes: rows prow and prow + 8 have py & 7 = prow, rows
+    // prow + 4 and prow + 12 have prow ^ 4, so two lane offsets computed once serve the four rows.
     auto stage_one = [&](int v) {
         global_byte* img = (global_byte*)(fb + v * img_stride);
         lds_byte* dst = (lds_byte*)(smem) + (v & 1) * kPatchBytes;
+        const int half = wave & 1, prow = wave >> 1;
+        const unsigned col = static_cast<unsigned>(min(ox[v] + (half << 3) + (lane >> 3), W - 1)) * kPixelBytes;
+        const unsigned sw = static_cast<unsigned>((lane & 7) ^ prow) << 4;
+        const unsigned voff0 = col + sw, voff1 = col + (sw ^ 64u);
 #pragma unroll
-        for (int it = 0; it < kPatchRows / 4; ++it) {
-            const int py = it * 4 + (wave >> 1);  // wave-uniform
+        for (int k = 0; k < kPatchRows / 4; ++k) {
+            const int py = k * 4 + prow;  // wave-uniform
             if (py < rows[v]) {
-                const int px = ((wave & 1) << 3) + (lane >> 3);
-                const int q = (lane & 7) ^ (py & 7);
-                const int gx = min(ox[v] + px, W - 1), gy = oy[v] + py;
-                const unsigned src = (static_cast<unsigned>(gy * W + gx) * C + static_cast<unsigned>(q) * 4u) * 4u;
-                __builtin_amdgcn_global_load_lds(img + src, dst + (py * kPatchW + ((wave & 1) << 3)) * kPixelBytes, 16,
-                                                 0, 0);
+                const unsigned row_off = static_cast<unsigned>((oy[v] + py) * W) * kPixelBytes;  // scalar
+                __builtin_amdgcn_global_load_lds(img + row_off + ((k & 1) ? voff1 : voff0),
+                                                 dst + (py * kPatchW + (half << 3)) * kPixelBytes, 16, 0, 0);
             }
         }
     };
