@@ -56,7 +56,6 @@ def algebraic_head():
     net = AlgebraicTriangulationNet.__new__(AlgebraicTriangulationNet)
     torch.nn.Module.__init__(net)
     net.use_confidences, net.heatmap_softmax, net.heatmap_multiplier = True, True, 100.0
-    net.reuse_outputs, net._arena = False, {}
     return net
 
 

@@ -261,6 +261,12 @@ def _inference_guard(module):
 
 
 class AlgebraicTriangulationNet(nn.Module):
+    # Not in the reference.  False: every call returns freshly allocated tensors, as the reference does.  True (for
+    # frame loops that finish with one frame's results before asking for the next, as real_pipeline_trt.py does): the
+    # output tensors of a call are kept per input shape and handed out again by the next call of that shape, which
+    # then allocates nothing -- results of an earlier call are overwritten by a later one.
+    reuse_outputs = False
+
     def __init__(self, config, device='cuda:0', backbone=None):
         super().__init__()
         self.use_confidences = config.model.use_confidences
@@ -272,12 +278,6 @@ class AlgebraicTriangulationNet(nn.Module):
         self.backbone = backbone if backbone is not None else _reference_backbone(config.model.backbone, device)
         self.heatmap_softmax = config.model.heatmap_softmax
         self.heatmap_multiplier = config.model.heatmap_multiplier
-        # Not in the reference.  False: every call returns freshly allocated tensors, as the reference does.  True
-        # (for frame loops that finish with one frame's results before asking for the next, as real_pipeline_trt.py
-        # does): the output tensors of a call are kept per input shape and handed out again by the next call of that
-        # shape, which then allocates nothing -- results of an earlier call are overwritten by a later one.
-        self.reuse_outputs = False
-        self._arena = {}
 
     def triangulate_from_heatmaps(self, heatmaps, alg_confidences, proj_matricies, image_shape):
         """Everything after the backbone: soft-argmax (multiplier folded in), confidence normalisation,
@@ -298,7 +298,8 @@ class AlgebraicTriangulationNet(nn.Module):
         _cabi.same_device(hm, "heatmaps", alg_confidences=conf, proj_matricies=proj)
         index = hm.device.index
         key = (b, v, j, h, w, index)
-        slot = self._arena.get(key) if self.reuse_outputs else None
+        arena = self.__dict__.setdefault("_arena", {}) if self.reuse_outputs else None   # (shape, device) -> outputs
+        slot = arena.get(key) if arena is not None else None
         if slot is None:
             hm_norm = torch.empty_like(hm)
             # one allocation for the small outputs: heatmap-pixel keypoints, image-pixel keypoints, confidences, joints
@@ -309,8 +310,8 @@ class AlgebraicTriangulationNet(nn.Module):
             # results, then the output pointers in the order mvx_algebraic_forward takes them
             slot = ((kp3d.view(b, j, 3), kp_img.view(b, v, j, 2), hm_norm, conf_norm.view(b, v, j)),
                     (hm_norm.data_ptr(), base + 4 * n2, base + 8 * n2, base + 8 * n2 + 4 * n1, base), small)
-            if self.reuse_outputs:
-                self._arena[key] = slot
+            if arena is not None:
+                arena[key] = slot
         results, out_ptrs, _ = slot
         lib = _cabi.load()
         # (device pointers travel as plain integers: the argument types declared for the entry point convert them)
