@@ -1027,10 +1027,12 @@ __global__ __launch_bounds__(kBrickThreads, 4) void unproject_brick32(const floa
     if (AGG == MVX_AGG_SOFTMAX) {
         // every denominator in [2^-80, 2^100] (a NaN fails both comparisons)
         if (!(chk_d.x + chk_d.y <= 0x1p100f) || !(chk_r.x + chk_r.y <= 0x1p80f)) sh->redo = 1;
-        // The stores above have left this wave before anybody stores the same voxels again.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // (a barrier that does not wait for the stores above: a wave may end with its stores still on their way)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (sh->redo != 0) {
+            // The stores above have left this wave before anybody stores the same voxels again.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             // weights and tap pixels once more (rather than kept in registers through the sampling above)
             int lz_again = lz;
             asm volatile("" : "+v"(lz_again));
