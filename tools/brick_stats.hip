@@ -26,8 +26,6 @@ int main(int argc, char** argv) {
 #ifdef MVX_BRICK_STATS
     unsigned zero[4] = {0, 0, 0, 0};
     hipMemcpyToSymbol(HIP_SYMBOL(mvx::brick_stats), zero, sizeof(zero));
-    unsigned long long zero8[8] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(mvx::brick_phase), zero8, sizeof(zero8));
 #endif
     // features: something other than zeros, so that the arithmetic is not trivial
     hipMemset(dfeat, 0x3c, static_cast<size_t>(B) * 4 * 32 * H * W * 4);
@@ -51,18 +49,11 @@ int main(int argc, char** argv) {
     return 0;
 #else
     hipMemcpyToSymbol(HIP_SYMBOL(mvx::brick_stats), zero, sizeof(zero));
-    hipMemcpyToSymbol(HIP_SYMBOL(mvx::brick_phase), zero8, sizeof(zero8));
     int rc = mvx_unproject_channels_last(dfeat, dproj, dcoord, nullptr, B, 4, 32, H, W, S, S, S, MVX_AGG_SOFTMAX, dvol, nullptr);
     hipDeviceSynchronize();
     unsigned st[4];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mvx::brick_stats), sizeof(st));
-    unsigned long long ph[8];
-    hipMemcpyFromSymbol(ph, HIP_SYMBOL(mvx::brick_phase), sizeof(ph));
-    const char* names[8] = {"setup + projection 0,1", "barrier", "rectangles + copy issue (pass 0)", "projection 2,3", "copy wait (pass 0)",
-                            "barrier + copy issue (pass 1)", "copy wait (pass 1)", "sampling (both passes)"};
-    unsigned long long total = 0;
-    for (int i = 0; i < 8; ++i) total += ph[i];
-    for (int i = 0; i < 8; ++i) printf("  %-32s %8.0f ticks per brick (%4.1f%%)\n", names[i], (double)ph[i] / st[0], 100.0 * ph[i] / total);
+    // (per-phase times: tools/brick_lab.hip built with -DMVX_BRICK_TRACE)
     printf("rc=%d bricks=%u direct=%u (%.2f%%) not-fitting=%u max rows=%u\n", rc, st[0], st[1], 100.0 * st[1] / (st[0] ? st[0] : 1), st[2], st[3]);
     return 0;
 #endif
