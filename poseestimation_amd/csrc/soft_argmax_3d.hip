@@ -732,7 +732,7 @@ int soft_argmax_3d_any(const float* volumes, const CoordSource& coord, bool inde
             double* records = static_cast<double*>(workspace);
             const int help_always = (kernel_selection() & MVX_SELECT_SOFT_ARGMAX_HELP_ALWAYS) ? 1 : 0;
             // cleared by a kernel of our own rather than hipMemsetAsync: captured into a HIP graph, the memset node
-            // took effect on the first replay only (ROCm 7.0), a kernel node replays like any other
+            // took effect on the first replay only (the HIP runtime of PyTorch 2.10 for ROCm 7), a kernel node replays like any other
             const size_t n_words = exchange_bytes / sizeof(unsigned long long);
             hipLaunchKernelGGL(clear_records, dim3(static_cast<unsigned>((n_words + kThreads - 1) / kThreads)), dim3(kThreads),
                                0, st, static_cast<unsigned long long*>(workspace), n_words);
