@@ -404,6 +404,37 @@ def test_unproject_brick_kernel_equals_tile_kernel(side, shape, views, no_bricks
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_unproject_brick_kernel_on_random_geometries(seed, no_bricks):
+    """Brick against tile kernel over cuboids of random size and position relative to the cameras, three and four views,
+    grids that are not cubes: bricks that fit their patches, bricks that do not, bricks only some of whose lanes fall
+    outside (the per-lane vote), frames that no camera sees."""
+    rng = np.random.default_rng(seed)
+    views = int(rng.choice([3, 4]))
+    side = float(rng.choice([700.0, 1800.0, 2500.0, 4000.0, 6000.0, 12000.0]))
+    case = synth.volumetric_case(seed, 3, views, volume_size=40, cuboid_side=side, with_volumes=False)
+    shape = (int(rng.choice([8, 16, 24, 40])), int(rng.choice([16, 32, 40])), int(rng.choice([8, 24, 40])))
+    feats, proj, vconf = (to_dev(case[k]) for k in ("features", "proj", "vol_confidences"))
+    coord = case["coord_volumes"][:, :shape[0], :shape[1], :shape[2]].copy()
+    coord[1] += rng.uniform(-1500, 1500, 3).astype(np.float32)     # one frame's cuboid pushed off-centre
+    coord[2] += np.float32(8000.0) * rng.choice([-1.0, 1.0])       # one far out of every camera's view or behind some
+    coord = to_dev(np.ascontiguousarray(coord))
+    for method in ("sum", "conf", "max", "softmax"):
+        no_bricks(False)
+        brick = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+        no_bricks(True)
+        tile = op.unproject_heatmaps(feats, proj, coord, method, vconf)
+        if method == "softmax":
+            assert torch.allclose(brick, tile, rtol=2e-6, atol=2e-6), (method, (brick - tile).abs().max().item())
+        else:
+            assert torch.equal(brick, tile), method
+    sub = np.arange(5, shape[0] * shape[1] * shape[2], 61)
+    ref = orc.unproject_heatmaps(case["features"], case["proj"], coord.cpu().numpy(), "softmax", case["vol_confidences"],
+                                 voxel_subset=sub)
+    got = brick.reshape(3, 32, -1)[:, :, sub].cpu().numpy()
+    assert np.abs(got - ref).max() <= UNPROJ_TOL
+
+
 def test_unproject_channels_last_input_is_sampled_in_place():
     """Feature maps in torch.channels_last memory give the same volumes, bit for bit, without the layout copy:
     the tile kernel (C = 32), the generic kernel (C = 8) and a C that is not a multiple of 4 (copied as usual)."""
