@@ -561,26 +561,27 @@ __global__ __launch_bounds__(kThreads) void unproject_tile32(const float* __rest
 }
 
 
-// ---- brick kernel: C = 32, four views, grid dimensions multiples of 8 ------------------------------------------
+// ---- brick kernel: C = 32, three or four views, grid dimensions multiples of 8 ------------------------------------
 // A workgroup of 512 threads owns a brick of 8 x 8 x 8 voxels, one voxel per lane.  Neighbouring voxels sample
-// neighbouring pixels, so the taps of a brick lie in a small patch of each view's map (about 13 x 12 pixels for the
+// neighbouring pixels, so the taps of a brick lie in a small patch of each view's map (about 11 x 11 pixels for the
 // camera set-up of the reference: one voxel is about one heatmap pixel); the patch is copied once into LDS and the
 // 2 x 2 x 32-channel taps are read from there: 512 bytes per voxel and view come out of LDS (256 B/clk per CU)
 // instead of the vector L1 (46 B/clk for this access shape), and about 13 times fewer bytes cross the L1.
-//   1. every lane projects its voxel into the four views (weights and tap pixel stay in its registers);
+//   1. every lane projects its voxel into the views (weights and tap pixel stay in its registers);
 //   2. the bounding box of the taps is taken from the brick's 8 corner voxels (exact for any grid whose voxel
 //      positions are affine in the voxel index and in front of the camera: the projection of a convex set is
 //      convex); every lane then checks its own taps against the box, so for anything else -- arbitrary coordinate
 //      tensors, a corner behind a camera, a patch larger than 16 x 16 pixels -- the whole brick takes the direct
-//      path (taps from global memory, same arithmetic);
-//   3. two passes of two views: the patches (rows of 16 pixels x 128 bytes) are copied global -> LDS by
-//      global_load_lds_dwordx4 (no registers, no VALU beyond the source address), the 16-byte channel quad q of a
-//      pixel in patch row py sits at position q ^ (py & 7) of the pixel's 128 bytes, so that the lanes of a wave --
-//      which read the same quad of pixels in different rows -- hit different banks;
+//      path (taps from global memory, the tile kernel's arithmetic);
+//   3. one unit per view: the patch of view v (rows of 16 pixels x 128 bytes) lives in LDS buffer v & 1, copied
+//      global -> LDS by global_load_lds_dwordx4 (no registers) while the unit before it is sampled; the 16-byte
+//      channel quad q of a pixel in patch row py sits at position q ^ (py & 7) of the pixel's 128 bytes, so that the
+//      lanes of a wave -- which read the same quad of pixels in different rows -- hit different banks;
 //   4. per channel quad a lane reads its taps with ds_read_b128 (the two taps of a row share one address, the
-//      second at +128 bytes), interpolates (packed FMA) and, in the second pass, aggregates the four views and
-//      stores: a wave's store of one channel covers 8 runs of 8 voxels (32 bytes each); bricks adjacent along z
-//      run back to back on one XCD and complete the 128-byte lines in its L2.
+//      second at +128 bytes), interpolates (packed FMA) and adds the view to its running aggregate; in the last unit
+//      it finishes the aggregate and stores: a wave's store of one channel covers 8 runs of 8 voxels (32 bytes
+//      each); bricks adjacent along z run back to back on one XCD and complete the 128-byte lines in its L2 (with
+//      z-neighbours on different XCDs the same stores take seven times as long).
 // The lane -> voxel map puts the 16 lanes that one ds_read_b128 cycle serves (lanes whose 4-lane chunks have an even,
 // respectively odd, number of set bits in the chunk index) on 2 (y) x 8 (z) voxels, i.e. on a column of pixels.
 constexpr int kBrick = 8;
