@@ -215,6 +215,42 @@ int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, 
                               void* stream);
 
 /*
+ * Backward of mvx_unproject: what torch autograd computes when the reference trains through
+ * mvn/utils/op.py:99-166 (train.py:281-290) -- the transpose of the bilinear sampling of every view (no gradient
+ * through taps outside a map, nor for voxels behind a camera, op.py:121,141), times the derivative of the view
+ * aggregation: 1 (sum), vol_conf (confidences), the first view that holds the maximum (max), or
+ * s_v (1 + x_v - out) with s the softmax over the views' samples x (softmax).  No gradient is produced for proj or
+ * coords.  float32 atomic additions in no fixed order: two runs agree to rounding, not to the bit.
+ * features_cl       [n_frames][n_views][h][w][Cp]     the forward call's maps, channel-last, Cp = n_channels rounded
+ *                                                     up to a multiple of 4 (padding = 0), 16-byte aligned; may be
+ *                                                     NULL for MVX_AGG_SUM, and for MVX_AGG_CONF without grad_vol_conf
+ * proj, coords, vol_conf                              as in mvx_unproject
+ * grad_volumes      [n_frames][n_channels][vx][vy][vz]
+ * grad_features_cl  [n_frames][n_views][h][w][Cp]     out, channel-last like features_cl; cleared by the call
+ * grad_vol_conf     [n_frames][n_views][n_channels]   out, MVX_AGG_CONF only (sum over the voxels of gradient x
+ *                                                     sample); cleared by the call; may be NULL
+ */
+int mvx_unproject_backward(const float* features_cl, const float* proj, const float* coords, const float* vol_conf,
+                           const float* grad_volumes, int64_t n_frames, int n_views, int n_channels, int h, int w, int vx,
+                           int vy, int vz, int aggregation, float* grad_features_cl, float* grad_vol_conf, void* stream);
+
+/*
+ * Backward of mvx_soft_argmax_3d: what torch autograd computes through mvn/utils/op.py:84-96 (coords_volume != NULL)
+ * or mvn/utils/op.py:50-81 (coords_volume == NULL: voxel indices, and for softmax == 0 the division by the mass).
+ * With p = volumes_out of the forward call and G_i = grad_volumes_out_i + grad_coordinates . X_i:
+ *   softmax != 0: grad_volumes_i = multiplier * p_i * (G_i - sum_j p_j G_j);  softmax == 0: multiplier * G_i where
+ *   p_i > 0 (index space: with X_i - out in place of X_i, divided by sum p).  Sums and G are float64.
+ * volumes_out        [n_frames][n_volumes][sx][sy][sz]  what the forward call wrote
+ * coords_volume      [n_frames][sx][sy][sz][3] or NULL
+ * grad_coordinates   [n_frames][n_volumes][3] or NULL (= zero)
+ * grad_volumes_out   [n_frames][n_volumes][sx][sy][sz] or NULL (= zero)
+ * grad_volumes       [n_frames][n_volumes][sx][sy][sz]  out: gradient of the forward call's `volumes`
+ */
+int mvx_soft_argmax_3d_backward(const float* volumes_out, const float* coords_volume, int64_t n_frames, int n_volumes,
+                                int sx, int sy, int sz, float multiplier, int softmax, const float* grad_coordinates,
+                                const float* grad_volumes_out, float* grad_volumes, void* stream);
+
+/*
  * Coordinate volumes of VolumetricTriangulationNet.forward: replaces the per-frame meshgrid / scale / rotate
  * loop of mvn/models/triangulation.py:341-385 (and mvn/utils/volumetric.py:102-114) with one launch.
  * For frame b and voxel (i0, i1, i2):  g = position[b] + step * (i0, i1, i2);  out = rotation[b] . (g - center[b])

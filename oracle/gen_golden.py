@@ -121,6 +121,37 @@ def gen_volumetric_full():
     return timing
 
 
+def gen_gradients():
+    """Gradients torch autograd derives through the reference's volumetric ops (what train.py:281-290 relies on) for
+    the small volumetric case and seeded upstream gradients: float32 as the reference runs, and the same code fed
+    float64."""
+    case = gc.small_volumetric_inputs()
+    feats, proj, coord, vconf, vols = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
+    up = gc.gradient_upstreams()
+    out = {"input_sha": gc.sha(feats, proj, coord, vconf, vols, up["volumes"], up["coords"], up["probs"])}
+    for dtype, tag in ((torch.float32, "ref32"), (torch.float64, "ref64")):
+        for m in gc.UNPROJECT_METHODS:
+            f = t(feats, dtype).requires_grad_(True)
+            c = t(vconf, dtype).requires_grad_(True)
+            vol = op.unproject_heatmaps(f, t(proj, dtype), t(coord, dtype), m, c)
+            (vol * t(up["volumes"], dtype)).sum().backward()
+            out["unproj_%s_gfeat_%s" % (m, tag)] = f.grad.numpy()
+            if m.startswith("conf"):
+                out["unproj_%s_gconf_%s" % (m, tag)] = c.grad.numpy()
+        for sm in (True, False):
+            for fn, name in ((lambda v: op.integrate_tensor_3d_with_coordinates(v, t(coord, dtype), softmax=sm), "int3dc"),
+                             (lambda v: op.integrate_tensor_3d(v, softmax=sm), "int3d")):
+                # the index-space ReLU divides by the mass: keep it away from zero
+                v = t(vols if name == "int3dc" or sm else vols + 0.5, dtype).requires_grad_(True)
+                coords, probs = fn(v)
+                ((coords * t(up["coords"], dtype)).sum() + (probs * t(up["probs"], dtype)).sum()).backward()
+                out["%s_%s_gvol_%s" % (name, "softmax" if sm else "relu", tag)] = v.grad.numpy()
+                v2 = v.detach().clone().requires_grad_(True)   # the coordinates alone (the volumes unused by the loss)
+                (fn(v2)[0] * t(up["coords"], dtype)).sum().backward()
+                out["%s_%s_gvol_coords_only_%s" % (name, "softmax" if sm else "relu", tag)] = v2.grad.numpy()
+    save("grads", **out)
+
+
 def gen_helpers():
     rng = np.random.default_rng(1400)
     K = np.array([[1145.0, 0, 512.3], [0, 1143.2, 515.9], [0, 0, 1]])
@@ -404,9 +435,10 @@ def gen_wire():
 if __name__ == "__main__":
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
-    if len(sys.argv) > 1:                     # regenerate selected fixtures only: ransac, datasets, savgol, wire
+    if len(sys.argv) > 1:                     # regenerate selected fixtures only: ransac, datasets, savgol, wire, grads
         for name in sys.argv[1:]:
-            {"ransac": gen_ransac, "datasets": gen_datasets, "savgol": gen_savgol, "wire": gen_wire}[name]()
+            {"ransac": gen_ransac, "datasets": gen_datasets, "savgol": gen_savgol, "wire": gen_wire,
+             "grads": gen_gradients}[name]()
         sys.exit(0)
     gen_wire()
     gen_ransac()
@@ -414,6 +446,7 @@ if __name__ == "__main__":
     gen_savgol()
     gen_algebraic()
     gen_volumetric_small()
+    gen_gradients()
     vol_timing = gen_volumetric_full()
     gen_helpers()
     gen_model_forward()

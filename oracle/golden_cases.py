@@ -68,6 +68,15 @@ def small_volumetric_inputs(seed=1300):
     return {"features": feats, "proj": proj, "coord_volumes": coord, "vol_confidences": vconf, "volumes": vols}
 
 
+def gradient_upstreams(seed=1310):
+    """Upstream gradients for the small volumetric case: of the unprojected volumes (B, C, X, Y, Z), of the 3-D
+    soft-argmax coordinates (B, J, 3) and of its normalised volumes (B, J, X, Y, Z)."""
+    rng = np.random.default_rng(seed)
+    return {"volumes": rng.standard_normal((2, 5, 6, 5, 7)).astype(np.float32),
+            "coords": rng.standard_normal((2, 3, 3)).astype(np.float32),
+            "probs": rng.standard_normal((2, 3, 6, 5, 7)).astype(np.float32)}
+
+
 FULL_VOL_SEED = 1237
 FULL_VOL_STRIDE = 251  # every 251st voxel of the 64^3 grid is kept in the fixture
 

@@ -282,6 +282,113 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
 
 
 # ----------------------------------------------------------------------------
+# gradients of the volumetric operations: what torch autograd derives through
+# mvn/utils/op.py:50-96 and :99-166 when the reference trains (train.py:281-290)
+# ----------------------------------------------------------------------------
+def _grid_sample_bilinear_zeros_transpose(grad, ix, iy, H, W):
+    """Transpose of _grid_sample_bilinear_zeros: grad (C, N) scattered to (C, H, W) with the same weights;
+    taps outside the map receive nothing (grid_sample's backward with zero padding)."""
+    x0 = np.floor(ix)
+    y0 = np.floor(iy)
+    wx1 = ix - x0
+    wy1 = iy - y0
+    out = np.zeros((grad.shape[0], H, W))
+    for dy, wy in ((0, 1.0 - wy1), (1, wy1)):
+        for dx, wx in ((0, 1.0 - wx1), (1, wx1)):
+            xx = x0 + dx
+            yy = y0 + dy
+            ok = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
+            xi = np.clip(xx, 0, W - 1).astype(np.int64)
+            yi = np.clip(yy, 0, H - 1).astype(np.int64)
+            for c in range(grad.shape[0]):
+                np.add.at(out[c], (yi, xi), grad[c] * wx * wy * ok)
+    return out
+
+
+def unproject_heatmaps_backward(heatmaps, proj_matricies, coord_volumes, grad_volumes, volume_aggregation_method="sum",
+                                vol_confidences=None):
+    """Gradients of unproject_heatmaps' output with respect to heatmaps (B,V,C,H,W) and vol_confidences (B,V,C),
+    given grad_volumes (B,C,X,Y,Z): float64.  Chain rule through op.py:150-162 (aggregation), op.py:141 (voxels
+    behind a camera are overwritten with 0: no gradient) and op.py:135 (grid_sample).  For "max" the gradient goes
+    to the first view that holds the maximum (torch.max(0) returns the first maximal index)."""
+    method = volume_aggregation_method
+    hm = np.asarray(heatmaps, dtype=np.float64)
+    P = np.asarray(proj_matricies, dtype=np.float64)
+    cv = np.asarray(coord_volumes, dtype=np.float64)
+    B, V, C, H, W = hm.shape
+    g_hm = np.zeros_like(hm)
+    g_conf = np.zeros((B, V, C)) if method.startswith("conf") else None
+    for b in range(B):
+        grid = cv[b].reshape(-1, 3)
+        g = np.asarray(grad_volumes, dtype=np.float64)[b].reshape(C, -1)
+        per_view = np.zeros((V, C, grid.shape[0]))
+        pix, invalid = [], []
+        for v in range(V):
+            uvw = np.hstack([grid, np.ones((grid.shape[0], 1))]) @ P[b, v].T
+            inv = uvw[:, 2] <= 0.0
+            z = np.where(uvw[:, 2] == 0.0, 1.0, uvw[:, 2])
+            ix = (uvw[:, 0] / z) / H * (W - 1)
+            iy = (uvw[:, 1] / z) / W * (H - 1)
+            vals = _grid_sample_bilinear_zeros(hm[b, v], ix, iy)
+            vals[:, inv] = 0.0
+            per_view[v] = vals
+            pix.append((ix, iy))
+            invalid.append(inv)
+        if method.startswith("conf"):
+            conf = np.asarray(vol_confidences, dtype=np.float64)[b]
+            d = g[None] * conf[:, :, None]
+            g_conf[b] = (g[None] * per_view).sum(2)
+        elif method == "sum":
+            d = np.broadcast_to(g[None], per_view.shape).copy()
+        elif method == "max":
+            first = per_view.argmax(0)
+            d = np.where(np.arange(V)[:, None, None] == first[None], g[None], 0.0)
+        elif method == "softmax":
+            e = np.exp(per_view - per_view.max(0, keepdims=True))
+            s = e / e.sum(0, keepdims=True)
+            out = (per_view * s).sum(0, keepdims=True)
+            d = g[None] * s * (1.0 + per_view - out)
+        else:
+            raise ValueError("Unknown volume_aggregation_method: {}".format(method))
+        for v in range(V):
+            dv = d[v].copy()
+            dv[:, invalid[v]] = 0.0
+            g_hm[b, v] = _grid_sample_bilinear_zeros_transpose(dv, pix[v][0], pix[v][1], H, W)
+    return g_hm, g_conf
+
+
+def integrate_tensor_3d_backward(volumes, coord_volumes, grad_coords, grad_volumes_out, softmax=True):
+    """Gradient with respect to `volumes` of integrate_tensor_3d_with_coordinates (coord_volumes given) or
+    integrate_tensor_3d (coord_volumes None: voxel indices, and the division by the mass for softmax=False,
+    op.py:73-76), for upstream gradients of the coordinates (B,n,3) and of the returned volumes (either may be None)."""
+    vol = np.asarray(volumes, dtype=np.float64)
+    B, n, sx, sy, sz = vol.shape
+    flat = vol.reshape(B, n, -1)
+    if coord_volumes is not None:
+        X = np.asarray(coord_volumes, dtype=np.float64).reshape(B, 1, -1, 3)
+    else:
+        idx = np.stack(np.meshgrid(np.arange(sx), np.arange(sy), np.arange(sz), indexing="ij"), axis=-1)
+        X = np.broadcast_to(idx.reshape(1, 1, -1, 3).astype(np.float64), (B, 1, sx * sy * sz, 3))
+    gc = np.zeros((B, n, 3)) if grad_coords is None else np.asarray(grad_coords, dtype=np.float64)
+    gp = np.zeros_like(flat) if grad_volumes_out is None else np.asarray(grad_volumes_out, dtype=np.float64).reshape(B, n, -1)
+    if softmax:
+        e = np.exp(flat - flat.max(axis=2, keepdims=True))
+        p = e / e.sum(axis=2, keepdims=True)
+        G = gp + np.einsum("bnc,bmkc->bnk", gc, X)
+        out = p * (G - (p * G).sum(axis=2, keepdims=True))
+    else:
+        p = np.maximum(flat, 0.0)
+        if coord_volumes is not None:
+            G = gp + np.einsum("bnc,bmkc->bnk", gc, X)
+        else:
+            mass = p.sum(axis=2, keepdims=True)
+            c = np.einsum("bnk,bmkc->bnc", p, X) / mass
+            G = gp + np.einsum("bnc,bnkc->bnk", gc, X - c[:, :, None, :]) / mass
+        out = np.where(flat > 0.0, G, 0.0)
+    return out.reshape(vol.shape)
+
+
+# ----------------------------------------------------------------------------
 # camera and coordinate-volume helpers
 # reference: mvn/utils/multiview.py:7-54, mvn/utils/volumetric.py:87-114,
 #            mvn/models/triangulation.py:341-377

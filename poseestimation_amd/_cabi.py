@@ -40,6 +40,9 @@ SIGNATURES = {
                                            _vp]),
     "mvx_unproject_grid": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _vp, _i64, _int, _int, _int, _int,
                                   _int, _int, _int, _int, _vp, _vp, _sz, _vp]),
+    "mvx_unproject_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp,
+                                      _vp]),
+    "mvx_soft_argmax_3d_backward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _vp]),
     "mvx_build_coord_volumes": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _f32, _f32, _int, _vp, _vp]),
     "mvx_soft_argmax_3d_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "mvx_soft_argmax_3d": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _sz, _vp]),
@@ -109,10 +112,15 @@ def same_device(ref, ref_name, **tensors):
                            % (name, t.device, ref_name, ref.device))
 
 
+def needs_grad(*tensors):
+    """True when autograd is recording and one of `tensors` requires grad."""
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
 def forward_only(what, *tensors):
-    """The kernels record no autograd graph.  Raises when autograd is recording and one of `tensors` requires
-    grad: returning a detached result there would drop the gradient without a word."""
-    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+    """For operations (or arguments of operations) that have no backward kernel.  Raises when autograd is recording
+    and one of `tensors` requires grad: returning a detached result there would drop the gradient without a word."""
+    if needs_grad(*tensors):
         raise MvxError("%s is forward-only (no backward kernel): call it under torch.no_grad() or detach its inputs; "
                        "training through this operation needs the reference's differentiable torch ops" % what)
 

@@ -6,9 +6,10 @@ the mvx HIP kernels.
 The heatmap backbone and the V2V volume network are not part of this package: they are taken from the
 reference's own `mvn.models.pose_resnet` / `mvn.models.v2v` when that tree is importable, or passed in
 (`backbone=`, `volume_net=`).  State-dict keys (`backbone.*`, `process_features.*`, `volume_net.*`) are the
-reference's, so its checkpoints load with strict=True.  Forward-only: the triangulation ops record no
-autograd graph (the reference's algebraic path is not differentiable either, mvn/utils/multiview.py:166);
-a module in training mode called with autograd recording raises instead of returning detached results.
+reference's, so its checkpoints load with strict=True.  The volumetric model trains as the reference's does
+(train.py:281-290): the unprojection and the 3-D soft-argmax have backward kernels for the maps, the view
+confidences and the volumes.  The algebraic and RANSAC heads are forward-only (soft-argmax + DLT have no backward
+kernel): such a module in training mode called with autograd recording raises instead of returning detached results.
 """
 import contextlib
 import random
@@ -253,10 +254,11 @@ class RANSACTriangulationNet(nn.Module):
 
 
 def _inference_guard(module):
-    """The triangulation kernels are forward-only.  A module in eval mode runs them without autograd, which is
-    what an inference caller of the reference gets under torch.no_grad().  A module in training mode does not
-    switch autograd off: the reference back-propagates through these steps (train.py:197-202, 281-290), so with
-    autograd recording the ops raise instead of handing back results that would silently train nothing."""
+    """A module in eval mode runs the triangulation kernels without autograd, which is what an inference caller of
+    the reference gets under torch.no_grad().  A module in training mode does not switch autograd off: the
+    reference back-propagates through these steps (train.py:197-202, 281-290), so with autograd recording the
+    volumetric ops record their backward, and the forward-only ones raise instead of handing back results that
+    would silently train nothing."""
     return contextlib.nullcontext() if module.training else torch.no_grad()
 
 

@@ -1,10 +1,14 @@
 """Same functions and signatures as the reference's mvn/utils/op.py, running on the mvx HIP kernels.
 
-All functions are forward-only (no autograd graph is recorded; they raise when autograd is recording and an
-input requires grad, rather than drop the gradient), take HIP device tensors and return freshly allocated
-float32 tensors on the same device, launched on torch's current stream.
+All functions take HIP device tensors and return freshly allocated float32 tensors on the same device, launched
+on torch's current stream.  The volumetric functions (unproject_heatmaps, integrate_tensor_3d,
+integrate_tensor_3d_with_coordinates) are differentiable with respect to what the reference trains through them --
+the maps, the view confidences and the volumes (train.py:281-290) -- by backward kernels of their own;
+integrate_tensor_2d, and projection matrices or coordinate volumes that require grad, have no backward kernel and
+raise when autograd is recording, rather than drop the gradient.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from poseestimation_amd import _cabi
 
@@ -77,9 +81,48 @@ def integrate_tensor_2d(heatmaps, softmax=True, *, multiplier=1.0, return_heatma
     return _soft_argmax_2d(heatmaps, softmax, multiplier, return_heatmaps)
 
 
+class _SoftArgmax3D(torch.autograd.Function):
+    """The 3-D soft-argmax with the backward torch autograd derives for mvn/utils/op.py:50-96 (gradient of both
+    outputs with respect to the volumes)."""
+
+    @staticmethod
+    def forward(ctx, volumes, coord_volumes, softmax, multiplier):
+        coords, out = _soft_argmax_3d_run(volumes, coord_volumes, softmax, multiplier, True)
+        cv = _cabi.device_f32(coord_volumes, "coord_volumes") if coord_volumes is not None else None
+        ctx.save_for_backward(out, cv)
+        ctx.softmax, ctx.multiplier = softmax, multiplier
+        ctx.set_materialize_grads(False)
+        return coords, out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_coords, grad_out):
+        out, cv = ctx.saved_tensors
+        if grad_coords is None and grad_out is None:
+            return None, None, None, None
+        b, n, sx, sy, sz = out.shape
+        gc = _cabi.device_f32(grad_coords, "grad_coords") if grad_coords is not None else None
+        go = _cabi.device_f32(grad_out, "grad_out") if grad_out is not None else None
+        grad = torch.empty_like(out)
+        with torch.cuda.device(out.device):
+            st = _cabi.load().mvx_soft_argmax_3d_backward(
+                _cabi.ptr(out), _cabi.ptr(cv), b, n, sx, sy, sz, float(ctx.multiplier), int(ctx.softmax), _cabi.ptr(gc),
+                _cabi.ptr(go), _cabi.ptr(grad), _cabi.stream(out.device))
+        _cabi.check(st, "mvx_soft_argmax_3d_backward")
+        return grad, None, None, None
+
+
 def _soft_argmax_3d(volumes, coord_volumes, softmax, multiplier, return_volumes):
-    _cabi.forward_only("integrate_tensor_3d" if coord_volumes is None else "integrate_tensor_3d_with_coordinates",
-                       volumes, coord_volumes)
+    name = "integrate_tensor_3d" if coord_volumes is None else "integrate_tensor_3d_with_coordinates"
+    _cabi.forward_only(name + " (coord_volumes)", coord_volumes)
+    if _cabi.needs_grad(volumes):
+        vol = volumes if volumes.dtype == torch.float32 else volumes.float()
+        coords, out = _SoftArgmax3D.apply(vol, coord_volumes, bool(softmax), float(multiplier))
+        return _as_input_dtype(volumes, coords, out if return_volumes else None)
+    return _soft_argmax_3d_run(volumes, coord_volumes, softmax, multiplier, return_volumes)
+
+
+def _soft_argmax_3d_run(volumes, coord_volumes, softmax, multiplier, return_volumes):
     vol = _cabi.device_f32(volumes, "volumes")
     if vol.dim() != 5:
         raise ValueError("volumes must have shape (batch, n_volumes, x, y, z), got %s" % (tuple(vol.shape),))
@@ -152,13 +195,73 @@ def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregati
     that layout.
     """
     method = volume_aggregation_method
+    _aggregation(method)
+    _cabi.forward_only("unproject_heatmaps (proj_matricies, coord_volumes)", proj_matricies, coord_volumes)
+    if _cabi.needs_grad(heatmaps, vol_confidences):
+        hm, vc = heatmaps, vol_confidences
+        if torch.is_tensor(hm) and hm.dtype != torch.float32:
+            hm = hm.float()
+        if torch.is_tensor(vc) and vc.dtype != torch.float32:
+            vc = vc.float()
+        volumes = _Unproject.apply(hm, proj_matricies, coord_volumes, vc, method)
+        return _as_input_dtype(heatmaps, volumes)[0]
+    return _unproject_run(heatmaps, proj_matricies, coord_volumes, method, vol_confidences)
+
+
+def _aggregation(method):
     if method.startswith('conf'):
-        agg = _cabi.AGG_CONF
-    elif method in _AGGREGATIONS:
-        agg = _AGGREGATIONS[method]
-    else:
-        raise ValueError("Unknown volume_aggregation_method: {}".format(method))
-    _cabi.forward_only("unproject_heatmaps", heatmaps, proj_matricies, coord_volumes, vol_confidences)
+        return _cabi.AGG_CONF
+    if method in _AGGREGATIONS:
+        return _AGGREGATIONS[method]
+    raise ValueError("Unknown volume_aggregation_method: {}".format(method))
+
+
+class _Unproject(torch.autograd.Function):
+    """The unprojection with the backward torch autograd derives for mvn/utils/op.py:99-166: gradients with respect
+    to the maps and, for the confidence aggregations, to the view confidences."""
+
+    @staticmethod
+    def forward(ctx, heatmaps, proj_matricies, coord_volumes, vol_confidences, method):
+        volumes = _unproject_run(heatmaps, proj_matricies, coord_volumes, method, vol_confidences)
+        ctx.save_for_backward(heatmaps, proj_matricies, coord_volumes, vol_confidences)
+        ctx.method = method
+        return volumes
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_volumes):
+        heatmaps, proj_matricies, coord_volumes, vol_confidences = ctx.saved_tensors
+        agg = _aggregation(ctx.method)
+        b, v, c, h, w = heatmaps.shape
+        cp = (c + 3) // 4 * 4
+        dev = heatmaps.device
+        want_conf = agg == _cabi.AGG_CONF and ctx.needs_input_grad[3]
+        feats_cl = None
+        if agg in (_cabi.AGG_MAX, _cabi.AGG_SOFTMAX) or want_conf:   # the kernel samples the maps again
+            if _is_channels_last(heatmaps):
+                feats_cl = heatmaps
+            else:   # channel-last copy, channels padded to a multiple of 4 with zeros
+                feats_cl = torch.zeros((b, v, h, w, cp), dtype=torch.float32, device=dev)
+                feats_cl[..., :c] = heatmaps.permute(0, 1, 3, 4, 2)
+        proj = _cabi.device_f32(proj_matricies, "proj_matricies")
+        cv = _cabi.device_f32(coord_volumes, "coord_volumes")
+        vc = _cabi.device_f32(vol_confidences, "vol_confidences") if agg == _cabi.AGG_CONF else None
+        grad = _cabi.device_f32(grad_volumes, "grad_volumes")
+        grad_cl = torch.empty((b, v, h, w, cp), dtype=torch.float32, device=dev)
+        grad_conf = torch.empty((b, v, c), dtype=torch.float32, device=dev) if want_conf else None
+        vshape = tuple(cv.shape[1:4])
+        with torch.cuda.device(dev):
+            st = _cabi.load().mvx_unproject_backward(
+                _cabi.ptr(feats_cl), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), _cabi.ptr(grad), b, v, c, h, w,
+                vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(grad_cl), _cabi.ptr(grad_conf), _cabi.stream(dev))
+        _cabi.check(st, "mvx_unproject_backward")
+        # logical (batch, views, channels, h, w) over the channel-last memory the kernel wrote
+        grad_maps = grad_cl[..., :c].permute(0, 1, 4, 2, 3) if ctx.needs_input_grad[0] else None
+        return grad_maps, None, None, grad_conf, None
+
+
+def _unproject_run(heatmaps, proj_matricies, coord_volumes, method, vol_confidences):
+    agg = _aggregation(method)
     channels_last = _is_channels_last(heatmaps)
     feats = heatmaps if channels_last else _cabi.device_f32(heatmaps, "heatmaps")
     proj = _cabi.device_f32(proj_matricies, "proj_matricies")

@@ -523,20 +523,18 @@ def test_volumetric_path_at_the_benchmark_size():
 
 
 def test_ops_refuse_to_drop_a_gradient():
-    """The kernels are forward-only.  An input that requires grad while autograd is recording would silently lose
-    its gradient (the reference's torch ops are differentiable), so the functions raise instead; under no_grad, or
-    for detached inputs, they run."""
+    """integrate_tensor_2d has no backward kernel.  An input that requires grad while autograd is recording would
+    silently lose its gradient (the reference's torch op is differentiable), so it raises instead; under no_grad, or
+    for detached inputs, it runs.  The volumetric functions record their backward (tests/test_backward_gpu.py) and
+    give the plain call's values."""
     case = synth.volumetric_case(5, 1, 2, n_joints=3, volume_size=8, with_volumes=True)
     f, p, c, v = (to_dev(case[k]) for k in ("features", "proj", "coord_volumes", "volumes"))
     hm = torch.randn(2, 3, 8, 8, device=dev())
     for t in (f, v, hm):
         t.requires_grad_(True)
-    with pytest.raises(_cabi.MvxError, match="forward-only"):
-        op.unproject_heatmaps(f, p, c, "sum")
-    with pytest.raises(_cabi.MvxError, match="forward-only"):
-        op.integrate_tensor_3d_with_coordinates(v, c)
-    with pytest.raises(_cabi.MvxError, match="forward-only"):
-        op.integrate_tensor_3d(v)
+    assert op.unproject_heatmaps(f, p, c, "sum").requires_grad
+    assert op.integrate_tensor_3d_with_coordinates(v, c)[0].requires_grad
+    assert op.integrate_tensor_3d(v)[0].requires_grad
     with pytest.raises(_cabi.MvxError, match="forward-only"):
         op.integrate_tensor_2d(hm)
     with torch.no_grad():

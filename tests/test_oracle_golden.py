@@ -140,3 +140,31 @@ def test_port_matches_reference_record():
     rec = json.load(open(os.path.join(gc.GOLDEN_DIR, "port_vs_reference.json")))
     assert rec["max_abs_diff_kp3d_mm"] == 0.0 and rec["max_abs_diff_kp2d_px"] == 0.0
     assert 0.5 < rec["port_s"] / rec["reference_s"] < 2.0
+
+
+def test_gradient_oracle_matches_the_reference_autograd():
+    """The oracle's backward restatements against the gradients torch autograd derived through the reference's own
+    unproject_heatmaps / integrate_tensor_3d[_with_coordinates] (tests/golden/grads.npz).  ref64 = the reference fed
+    float64 tensors (its per-view buffers stay float32, hence 2e-7 rather than 1e-12 for softmax / conf)."""
+    g = load("grads")
+    case = gc.small_volumetric_inputs()
+    up = gc.gradient_upstreams()
+    feats, proj, coord, vconf, vols = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
+    assert gc.sha(feats, proj, coord, vconf, vols, up["volumes"], up["coords"], up["probs"]) == str(g["input_sha"])
+    for m in gc.UNPROJECT_METHODS:
+        g_maps, g_conf = orc.unproject_heatmaps_backward(feats, proj, coord, up["volumes"], m, vconf)
+        np.testing.assert_allclose(g_maps, g["unproj_%s_gfeat_ref64" % m], rtol=0, atol=3e-7)
+        assert np.abs(g_maps - g["unproj_%s_gfeat_ref32" % m]).max() < 5e-5
+        if m.startswith("conf"):
+            np.testing.assert_allclose(g_conf, g["unproj_%s_gconf_ref64" % m], rtol=0, atol=2e-6)
+        else:
+            assert g_conf is None
+    for sm in (True, False):
+        tag = "softmax" if sm else "relu"
+        for cv, v, name in ((coord, vols, "int3dc"), (None, vols if sm else vols + np.float32(0.5), "int3d")):
+            out = orc.integrate_tensor_3d_backward(v, cv, up["coords"], up["probs"], sm)
+            np.testing.assert_allclose(out, g["%s_%s_gvol_ref64" % (name, tag)], rtol=1e-12, atol=1e-11)
+            ref32 = g["%s_%s_gvol_ref32" % (name, tag)]
+            assert np.abs(out - ref32).max() <= 1e-6 * np.abs(ref32).max()
+            out = orc.integrate_tensor_3d_backward(v, cv, up["coords"], None, sm)
+            np.testing.assert_allclose(out, g["%s_%s_gvol_coords_only_ref64" % (name, tag)], rtol=1e-12, atol=1e-11)
