@@ -82,7 +82,7 @@ class EventTimer:
 KERNEL_SOURCES = {   # the files a kernel is compiled from: a counter record is valid for exactly these bytes
     "soft_argmax_2d_reg<9>": ("soft_argmax_2d.hip", "mvx_common.h"),
     "heatmap_argmax<9>": ("ransac.hip", "mvx_common.h"),
-    "unproject": ("unproject.hip", "grid_coords.h", "mvx_common.h"),
+    "unproject": ("unproject.hip", "unproject_taps.h", "grid_coords.h", "mvx_common.h"),
     "soft_argmax_3d": ("soft_argmax_3d.hip", "grid_coords.h", "mvx_common.h"),
 }
 

@@ -56,6 +56,8 @@ const char* mvx_last_error(void);
 #define MVX_SELECT_SOFT_ARGMAX_HELP_ALWAYS 8u /* one-read kernel: every workgroup recomputes its team-mates' partial
                                                  sums itself instead of reading them (the path it otherwise takes
                                                  only for a team-mate that is not resident) */
+#define MVX_SELECT_NO_BACKWARD_IN_LDS 16u /* mvx_unproject_backward: gradient slices accumulated in LDS off (global
+                                             atomics, the any-shape kernel) */
 void mvx_set_kernel_selection(unsigned mask);
 
 /*
@@ -220,19 +222,28 @@ int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, 
  * through taps outside a map, nor for voxels behind a camera, op.py:121,141), times the derivative of the view
  * aggregation: 1 (sum), vol_conf (confidences), the first view that holds the maximum (max), or
  * s_v (1 + x_v - out) with s the softmax over the views' samples x (softmax).  No gradient is produced for proj or
- * coords.  float32 atomic additions in no fixed order: two runs agree to rounding, not to the bit.
+ * coords.
  * features_cl       [n_frames][n_views][h][w][Cp]     the forward call's maps, channel-last, Cp = n_channels rounded
  *                                                     up to a multiple of 4 (padding = 0), 16-byte aligned; may be
  *                                                     NULL for MVX_AGG_SUM, and for MVX_AGG_CONF without grad_vol_conf
  * proj, coords, vol_conf                              as in mvx_unproject
  * grad_volumes      [n_frames][n_channels][vx][vy][vz]
- * grad_features_cl  [n_frames][n_views][h][w][Cp]     out, channel-last like features_cl; cleared by the call
+ * grad_features_cl  [n_frames][n_views][h][w][Cp]     out, channel-last like features_cl; every element written
  * grad_vol_conf     [n_frames][n_views][n_channels]   out, MVX_AGG_CONF only (sum over the voxels of gradient x
- *                                                     sample); cleared by the call; may be NULL
+ *                                                     sample); written by the call; may be NULL
+ * workspace         mvx_unproject_backward_workspace_bytes() bytes of device memory, 16-byte aligned: for MVX_AGG_MAX
+ *                   and MVX_AGG_SOFTMAX, what the aggregation needs of all views at a voxel (first maximal view;
+ *                   log-sum-exp and aggregate), 8 or 16 bytes per (channel pair, voxel); 0 bytes otherwise (NULL allowed)
+ * Maps of up to about 9 600 pixels (96 x 96 fits) and up to 16 views accumulate slices of the gradient in LDS, in
+ * float64, and are written once (no atomics in global memory; two runs agree except for float64 rounding before the
+ * final conversion); other shapes use float32 atomic additions in global memory in no fixed order.
  */
+size_t mvx_unproject_backward_workspace_bytes(int64_t n_frames, int n_views, int n_channels, int h, int w, int vx, int vy,
+                                              int vz, int aggregation);
 int mvx_unproject_backward(const float* features_cl, const float* proj, const float* coords, const float* vol_conf,
                            const float* grad_volumes, int64_t n_frames, int n_views, int n_channels, int h, int w, int vx,
-                           int vy, int vz, int aggregation, float* grad_features_cl, float* grad_vol_conf, void* stream);
+                           int vy, int vz, int aggregation, float* grad_features_cl, float* grad_vol_conf,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Backward of mvx_soft_argmax_3d: what torch autograd computes through mvn/utils/op.py:84-96 (coords_volume != NULL)
@@ -245,10 +256,14 @@ int mvx_unproject_backward(const float* features_cl, const float* proj, const fl
  * grad_coordinates   [n_frames][n_volumes][3] or NULL (= zero)
  * grad_volumes_out   [n_frames][n_volumes][sx][sy][sz] or NULL (= zero)
  * grad_volumes       [n_frames][n_volumes][sx][sy][sz]  out: gradient of the forward call's `volumes`
+ * workspace          mvx_soft_argmax_3d_backward_workspace_bytes() bytes of device memory, 8-byte aligned (partial sums
+ *                    of the segments a volume is cut into; not used for softmax == 0 with coords_volume)
  */
+size_t mvx_soft_argmax_3d_backward_workspace_bytes(int64_t n_frames, int n_volumes, int sx, int sy, int sz);
 int mvx_soft_argmax_3d_backward(const float* volumes_out, const float* coords_volume, int64_t n_frames, int n_volumes,
                                 int sx, int sy, int sz, float multiplier, int softmax, const float* grad_coordinates,
-                                const float* grad_volumes_out, float* grad_volumes, void* stream);
+                                const float* grad_volumes_out, float* grad_volumes, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /*
  * Coordinate volumes of VolumetricTriangulationNet.forward: replaces the per-frame meshgrid / scale / rotate

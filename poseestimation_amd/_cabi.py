@@ -18,6 +18,7 @@ SELECT_NO_UNPROJECT_BRICKS = 1
 SELECT_NO_DLT_ROWS = 2
 SELECT_NO_SOFT_ARGMAX_RESIDENT = 4
 SELECT_SOFT_ARGMAX_HELP_ALWAYS = 8
+SELECT_NO_BACKWARD_IN_LDS = 16
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _i64, _int, _f32, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
@@ -40,9 +41,12 @@ SIGNATURES = {
                                            _vp]),
     "mvx_unproject_grid": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _vp, _i64, _int, _int, _int, _int,
                                   _int, _int, _int, _int, _vp, _vp, _sz, _vp]),
+    "mvx_unproject_backward_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int, _int, _int, _int]),
     "mvx_unproject_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp,
-                                      _vp]),
-    "mvx_soft_argmax_3d_backward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _vp]),
+                                      _vp, _sz, _vp]),
+    "mvx_soft_argmax_3d_backward_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
+    "mvx_soft_argmax_3d_backward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _vp, _sz,
+                                           _vp]),
     "mvx_build_coord_volumes": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _f32, _f32, _int, _vp, _vp]),
     "mvx_soft_argmax_3d_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "mvx_soft_argmax_3d": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _int, _vp, _vp, _vp, _sz, _vp]),

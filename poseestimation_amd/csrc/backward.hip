@@ -3,19 +3,38 @@
 // over views) and integrate_tensor_3d / integrate_tensor_3d_with_coordinates (mvn/utils/op.py:50-96: softmax or ReLU,
 // then the expectation of the coordinates); the reference's training step is train.py:281-290.
 //
-// Unprojection: one lane per voxel.  The lane projects its voxel into every view with the forward kernels' own
-// routine (unproject_taps.h: the same taps, the same weights), samples the maps again where the aggregation needs
-// the sampled values (max, softmax, and the gradient of the confidences), and adds weight x gradient to the four
-// taps of every channel with float32 atomic adds at agent scope into a channel-last gradient [frame][view][h][w][Cp]
-// that the entry point has zeroed.  The order of those additions is not fixed: two runs differ in the last bits.
+// Unprojection.  A lane projects its voxel with the forward kernels' own routine (unproject_taps.h: the same taps,
+// the same weights) and adds weight x gradient x (derivative of the view aggregation) to the four taps of every
+// channel of a channel-last gradient [frame][view][h][w][Cp].
+//   unproject_backward_maps  one 1024-thread workgroup per (frame, view, 2 channels) keeps that slice of the gradient
+//                            -- the whole h x w map in float64, 145 KB for 96 x 96 -- in LDS, walks all voxels of the
+//                            frame adding into it with LDS atomics, and writes the slice once, rounded to float32, with
+//                            plain stores.  No global atomics, no clearing pass; for maps of up to about 9 600 pixels
+//                            and up to 16 views.  float64 because that is the fast LDS atomic on gfx950: ds_add_f64
+//                            retires 4 to 7 lanes per clock per CU, ds_add_f32 one lane per 3 clocks whatever the
+//                            addresses (tools/lds_atomic_rate.hip) -- and the sums come out exact to float32 rounding.
+//                            Rows of the slice are padded by one element: the voxels of a wave lie along one grid
+//                            axis and project onto a line of pixels, and with rows of 2 W doubles a vertical line
+//                            would fall into one pair of LDS banks.
+//   unproject_view_stats     max and softmax only, before the kernel above: what those aggregations need of ALL views
+//                            at a voxel -- the index of the first maximal view, or log-sum-exp and the aggregated
+//                            value -- written once per (channel pair, voxel) into the workspace, so that each slice
+//                            samples its own view only (without it: 16 x 4 slices each sample 4 views, 8.2 ms for
+//                            8 frames instead of 2).
+//   unproject_backward       any shape: one lane per voxel, float32 atomic adds at agent scope into a gradient the
+//                            entry point has zeroed (for 8 frames of the model's shape 52 ms: every addition is a
+//                            round trip to the memory side, and their order is not fixed: two runs differ in the last
+//                            bits).
 //
-// 3-D soft-argmax: one workgroup per volume.  With p the forward's output volume, X_i the coordinates of voxel i,
-// gc the gradient of the volume's coordinates and gp_i the gradient of p_i, G_i = gp_i + gc . X_i and
+// 3-D soft-argmax.  With p the forward's output volume, X_i the coordinates of voxel i, gc the gradient of the
+// volume's coordinates and gp_i the gradient of p_i, G_i = gp_i + gc . X_i and
 //   softmax:                 dL/dx_i = m p_i (G_i - sum_j p_j G_j)
 //   ReLU (with coordinates): dL/dx_i = m G_i where p_i > 0
 //   ReLU (index space, where the reference divides the coordinates by the mass M = sum p; c = the coordinates):
 //                            dL/dx_i = m (gp_i + gc . (X_i - c) / M) where p_i > 0
-// (m = the multiplier folded into the forward call).  G and the sums are float64.
+// (m = the multiplier folded into the forward call).  G and the sums are float64.  A volume is cut into segments so
+// that a training batch of a few frames still fills the chip: one kernel leaves each segment's partial sums in the
+// workspace, the next adds them up (in a fixed order) and writes its segment.
 #include "grid_coords.h"
 #include "unproject_taps.h"
 
@@ -24,7 +43,6 @@ namespace mvx {
 namespace {
 
 constexpr int kBackwardThreads = 256;
-constexpr int kVolumeThreads = 1024;
 
 __device__ __forceinline__ void load_camera(const float* __restrict__ proj, int64_t bv, double sx, double sy,
                                             double (&Pd)[12]) {
@@ -163,70 +181,243 @@ __global__ __launch_bounds__(kBackwardThreads) void unproject_backward(
     }
 }
 
-// Sum over the workgroup, returned to every thread.  `slots`: kVolumeThreads / 64 doubles of LDS per value.
-template <int N>
-__device__ __forceinline__ void block_sums(double (&v)[N], double* slots) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+constexpr int kMapsThreads = 1024;
+constexpr int kMapsMaxViews = 16;
+constexpr size_t kMapsMaxSliceBytes = 152 * 1024;
+
+__host__ __device__ inline int slice_row(int W) { return 2 * W + 1; }  // doubles per padded row of a slice
+
+// Per (frame, channel pair, voxel), for the slices of the kernel below.  softmax: float4 {L0, out0, L1, out1} with
+// L = log sum_u exp(x_u) and out = sum_u softmax(x)_u x_u of the pair's two channels; max: float2 with the index of
+// the first view that holds the maximum.  One lane per voxel, the channels four quads at a time.
+template <int AGG>
+__global__ __launch_bounds__(kBackwardThreads) void unproject_view_stats(
+    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, int64_t n_total, int V, int Cp,
+    int H, int W, int64_t n_vox, double sx, double sy, float* __restrict__ stats) {
+    __shared__ double cam[kMapsMaxViews * 12];
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBackwardThreads + threadIdx.x;
+    // a workgroup may straddle two frames: the cameras are then read per lane from global memory instead
+    const int64_t b_first = (static_cast<int64_t>(blockIdx.x) * kBackwardThreads) / n_vox;
+    const int64_t last = static_cast<int64_t>(blockIdx.x) * kBackwardThreads + kBackwardThreads - 1;
+    const bool one_frame = (last < n_total ? last : n_total - 1) / n_vox == b_first;
+    if (one_frame && threadIdx.x < V * 12)
+        cam[threadIdx.x] = camera_entry(proj + (b_first * V + threadIdx.x / 12) * 12, threadIdx.x % 12, sx, sy);
+    __syncthreads();
+    if (idx >= n_total) return;
+    const int64_t b = idx / n_vox, n = idx - b * n_vox;
+    double X, Y, Z;
+    voxel_position(coord, b, n_vox, n, X, Y, Z);
+    const size_t map = static_cast<size_t>(H) * W * Cp;
+    const int Cq = Cp / 4, pairs = Cp / 2;
+    for (int q0 = 0; q0 < Cq; q0 += 4) {
+        float top[4][4], den[4][4], num[4][4];
+        int first[4][4];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const double s = wave_sum(v[i]);
-        if (lane == 0) slots[i * (kVolumeThreads / 64) + wave] = s;
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                top[j][k] = -INFINITY;
+                den[j][k] = 0.0f;
+                num[j][k] = 0.0f;
+                first[j][k] = 0;
+            }
+        }
+        for (int u = 0; u < V; ++u) {
+            Tap t;
+            if (one_frame) {
+                t = project_tap(cam + u * 12, X, Y, Z, H, W, 1.0f);
+            } else {
+                double Pd[12];
+                load_camera(proj, b * V + u, sx, sy, Pd);
+                t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (q0 + j >= Cq) continue;  // uniform
+                float val[4];
+                sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q0 + j, val);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (AGG == MVX_AGG_MAX) {
+                        const bool up = (u == 0) || (val[k] > top[j][k]);  // strictly greater: the first maximal view stays
+                        first[j][k] = up ? u : first[j][k];
+                        top[j][k] = up ? val[k] : top[j][k];
+                    } else {  // running maximum; what is summed so far is rescaled when it moves
+                        const float dd = val[k] - top[j][k];
+                        const float r = exp_neg(-fabsf(dd));
+                        const bool up = dd > 0.0f;
+                        const float keep = up ? r : 1.0f, e = up ? 1.0f : r;
+                        den[j][k] = fmaf(den[j][k], keep, e);
+                        num[j][k] = fmaf(num[j][k], keep, e * val[k]);
+                        top[j][k] = up ? val[k] : top[j][k];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (q0 + j >= Cq) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t at = (static_cast<size_t>(b) * pairs + 2 * (q0 + j) + h) * n_vox + n;
+                if (AGG == MVX_AGG_MAX) {
+                    reinterpret_cast<float2*>(stats)[at] =
+                        make_float2(static_cast<float>(first[j][2 * h]), static_cast<float>(first[j][2 * h + 1]));
+                } else {
+                    reinterpret_cast<float4*>(stats)[at] =
+                        make_float4(top[j][2 * h] + logf(den[j][2 * h]), num[j][2 * h] / den[j][2 * h],
+                                    top[j][2 * h + 1] + logf(den[j][2 * h + 1]), num[j][2 * h + 1] / den[j][2 * h + 1]);
+                }
+            }
+        }
+    }
+}
+
+// One workgroup per (frame, view, channel pair): the slice [h][w][2] of the gradient lives in LDS as float64, rows
+// padded to slice_row(W).  Dynamic LDS: H * slice_row(W) doubles.  Channels c0 = 4q + 2 * half and c0 + 1.
+template <int AGG>
+__global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
+    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord,
+    const float* __restrict__ vconf, const float* __restrict__ g_vol, const float* __restrict__ stats, int V, int C,
+    int Cp, int H, int W, int64_t n_vox, double sx, double sy, float* __restrict__ g_feat_cl,
+    float* __restrict__ g_conf) {
+    extern __shared__ double slice[];
+    __shared__ double cam[12];
+    __shared__ double sums[2 * (kMapsThreads / 64)];
+    const int tid = threadIdx.x;
+    const int pairs = Cp / 2;
+    unsigned id = blockIdx.x;
+    const int pair = static_cast<int>(id % pairs);
+    id /= pairs;
+    const int v = static_cast<int>(id % V);
+    const int64_t b = id / V;
+    const int q = pair >> 1, half = pair & 1, c0 = 2 * pair;  // c0 + 1 may be padding
+    const int RS = slice_row(W);
+    for (int i = tid; i < H * RS; i += kMapsThreads) slice[i] = 0.0;
+    if (tid < 12) cam[tid] = camera_entry(proj + (b * V + v) * 12, tid, sx, sy);
+    __syncthreads();
+    const size_t map = static_cast<size_t>(H) * W * Cp;
+    const float* img = feat_cl + (b * V + v) * map;
+    constexpr bool kNeedsValues = AGG == MVX_AGG_MAX || AGG == MVX_AGG_SOFTMAX;
+    const bool wants_conf = AGG == MVX_AGG_CONF && g_conf != nullptr;
+    float conf[2] = {0.0f, 0.0f};
+    if (AGG == MVX_AGG_CONF) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) conf[k] = (c0 + k < C) ? vconf[(b * V + v) * C + c0 + k] : 0.0f;
+    }
+    double conf_grad[2] = {0.0, 0.0};
+    for (int64_t n = tid; n < n_vox; n += kMapsThreads) {
+        double X, Y, Z;
+        voxel_position(coord, b, n_vox, n, X, Y, Z);
+        float g[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) g[k] = (c0 + k < C) ? g_vol[(b * C + c0 + k) * n_vox + n] : 0.0f;
+        const TapXY t = project_tap_xy(cam, X, Y, Z, H, W, 1.0f);
+        float d[2];
+        if (kNeedsValues || wants_conf) {
+            Tap tp;
+            tp.w00 = t.w00;
+            tp.w01 = t.w01;
+            tp.w10 = t.w10;
+            tp.w11 = t.w11;
+            tp.pixel = static_cast<unsigned>(t.yb * W + t.xb);
+            float quad[4];
+            sample_quad(img, tp, W, Cp, q, quad);
+            const float mine[2] = {half ? quad[2] : quad[0], half ? quad[3] : quad[1]};
+            if (AGG == MVX_AGG_MAX) {
+                const float2 first = reinterpret_cast<const float2*>(stats)[(static_cast<size_t>(b) * pairs + pair) * n_vox + n];
+                d[0] = static_cast<int>(first.x) == v ? g[0] : 0.0f;
+                d[1] = static_cast<int>(first.y) == v ? g[1] : 0.0f;
+            } else if (AGG == MVX_AGG_SOFTMAX) {
+                // out = sum_u s_u x_u with s = softmax(x):  d out / d x_v = s_v (1 + x_v - out),  s_v = exp(x_v - L)
+                const float4 st = reinterpret_cast<const float4*>(stats)[(static_cast<size_t>(b) * pairs + pair) * n_vox + n];
+                d[0] = g[0] * exp_neg(fminf(mine[0] - st.x, 0.0f)) * (1.0f + mine[0] - st.y);
+                d[1] = g[1] * exp_neg(fminf(mine[1] - st.z, 0.0f)) * (1.0f + mine[1] - st.w);
+            } else {
+                d[0] = g[0] * conf[0];
+                d[1] = g[1] * conf[1];
+                conf_grad[0] += static_cast<double>(g[0] * mine[0]);
+                conf_grad[1] += static_cast<double>(g[1] * mine[1]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) d[k] = AGG == MVX_AGG_CONF ? g[k] * conf[k] : g[k];
+        }
+        double* p = slice + t.yb * RS + 2 * t.xb;
+        const float w4[4] = {t.w00, t.w01, t.w10, t.w11};
+        const int off[4] = {0, 2, RS, RS + 2};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (w4[i] == 0.0f) continue;  // outside the map, or behind the camera: the reference passes no gradient
+#pragma unroll
+            for (int k = 0; k < 2; ++k) atomicAdd(p + off[i] + k, static_cast<double>(d[k]) * static_cast<double>(w4[i]));
+        }
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double s = 0.0;
-        for (int w = 0; w < waves; ++w) s += slots[i * (kVolumeThreads / 64) + w];
-        v[i] = s;
+    float* out = g_feat_cl + (b * V + v) * map + c0;
+    for (int i = tid; i < H * W; i += kMapsThreads) {
+        const int y = i / W, x = i - y * W;
+        const double* e = slice + y * RS + 2 * x;
+        *reinterpret_cast<float2*>(out + static_cast<size_t>(i) * Cp) = make_float2(static_cast<float>(e[0]), static_cast<float>(e[1]));
     }
-    __syncthreads();
+    if (wants_conf) {
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double sw = wave_sum(conf_grad[k]);
+            if (lane == 0) sums[k * (kMapsThreads / 64) + wave] = sw;
+        }
+        __syncthreads();
+        if (tid < 2 && c0 + tid < C) {
+            double total = 0.0;
+            for (int w = 0; w < kMapsThreads / 64; ++w) total += sums[tid * (kMapsThreads / 64) + w];
+            g_conf[(b * V + v) * C + c0 + tid] = static_cast<float>(total);
+        }
+    }
+}
+
+// ---- 3-D soft-argmax ------------------------------------------------------------------------------------------
+constexpr int kVolumeThreads = 512;
+constexpr int kMaxSegments = 16;
+
+// Position of voxel i: its coordinates, or its indices.
+__device__ __forceinline__ void voxel_xyz(const float* __restrict__ xyz, int64_t i, int vy, int vz, double (&x)[3]) {
+    if (xyz != nullptr) {
+        x[0] = xyz[3 * i];
+        x[1] = xyz[3 * i + 1];
+        x[2] = xyz[3 * i + 2];
+    } else {
+        const int64_t row = i / vz;
+        x[2] = static_cast<double>(i - row * vz);
+        x[0] = static_cast<double>(row / vy);
+        x[1] = static_cast<double>(row - (row / vy) * vy);
+    }
 }
 
 // mode 0: softmax; 1: ReLU, coordinates not divided by the mass; 2: ReLU, coordinates divided by the mass.
-// coords: [frames][N][3], or null for the voxel indices themselves.
-__global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward(
+// Workgroup (volume, segment) leaves in partial[(volume * segments + segment) * 4 ..]: mode 0 sum p G; mode 2 the
+// mass and the first moments of p.
+__global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_sums(
     const float* __restrict__ probs, const float* __restrict__ coords, int n_volumes, int vy, int vz, int64_t N,
-    float multiplier, int mode, const float* __restrict__ g_coords, const float* __restrict__ g_probs,
-    float* __restrict__ g_volumes) {
+    int segments, int64_t seg_len, int mode, const float* __restrict__ g_coords, const float* __restrict__ g_probs,
+    double* __restrict__ partial) {
     __shared__ double slots[4 * (kVolumeThreads / 64)];
-    const int64_t vol = blockIdx.x;
+    const int64_t vol = blockIdx.x / segments;
+    const int seg = blockIdx.x % segments;
     const int64_t frame = vol / n_volumes;
     const float* p = probs + vol * N;
     const float* gp = g_probs != nullptr ? g_probs + vol * N : nullptr;
     const float* xyz = coords != nullptr ? coords + frame * N * 3 : nullptr;
-    float* gx = g_volumes + vol * N;
     double gc[3] = {0.0, 0.0, 0.0};
     if (g_coords != nullptr) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) gc[a] = g_coords[vol * 3 + a];
     }
-    auto position = [&](int64_t i, double (&x)[3]) {
-        if (xyz != nullptr) {
-            x[0] = xyz[3 * i];
-            x[1] = xyz[3 * i + 1];
-            x[2] = xyz[3 * i + 2];
-        } else {
-            const int64_t row = i / vz;
-            x[2] = static_cast<double>(i - row * vz);
-            x[0] = static_cast<double>(row / vy);
-            x[1] = static_cast<double>(row - (row / vy) * vy);
-        }
-    };
-    const double m = static_cast<double>(multiplier);
-    if (mode == 1) {
-        for (int64_t i = threadIdx.x; i < N; i += kVolumeThreads) {
-            double x[3];
-            position(i, x);
-            const double G = (gp != nullptr ? static_cast<double>(gp[i]) : 0.0) + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
-            gx[i] = p[i] > 0.0f ? static_cast<float>(m * G) : 0.0f;
-        }
-        return;
-    }
-    // first sweep: softmax: sum p G; normalised ReLU: the mass and the first moments
+    const int64_t i0 = seg * seg_len, i1 = (i0 + seg_len < N) ? i0 + seg_len : N;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t i = threadIdx.x; i < N; i += kVolumeThreads) {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kVolumeThreads) {
         double x[3];
-        position(i, x);
+        voxel_xyz(xyz, i, vy, vz, x);
         const double pi = p[i];
         if (mode == 0) {
             const double G = (gp != nullptr ? static_cast<double>(gp[i]) : 0.0) + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
@@ -238,36 +429,98 @@ __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward(
             s[3] += pi * x[2];
         }
     }
-    block_sums(s, slots);
-    if (mode == 0) {
-        const double dot = s[0];
-        for (int64_t i = threadIdx.x; i < N; i += kVolumeThreads) {
-            double x[3];
-            position(i, x);
-            const double G = (gp != nullptr ? static_cast<double>(gp[i]) : 0.0) + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
-            gx[i] = static_cast<float>(m * static_cast<double>(p[i]) * (G - dot));
-        }
-    } else {
-        const double mass = s[0];
-        const double c[3] = {s[1] / mass, s[2] / mass, s[3] / mass};
-        for (int64_t i = threadIdx.x; i < N; i += kVolumeThreads) {
-            double x[3];
-            position(i, x);
-            const double G = (gp != nullptr ? static_cast<double>(gp[i]) : 0.0) +
-                             (gc[0] * (x[0] - c[0]) + gc[1] * (x[1] - c[1]) + gc[2] * (x[2] - c[2])) / mass;
-            gx[i] = p[i] > 0.0f ? static_cast<float>(m * G) : 0.0f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double w = wave_sum(s[k]);
+        if (lane == 0) slots[k * (kVolumeThreads / 64) + wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double total = 0.0;
+        for (int w = 0; w < kVolumeThreads / 64; ++w) total += slots[threadIdx.x * (kVolumeThreads / 64) + w];
+        partial[(vol * segments + seg) * 4 + threadIdx.x] = total;
+    }
+}
+
+__global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_write(
+    const float* __restrict__ probs, const float* __restrict__ coords, int n_volumes, int vy, int vz, int64_t N,
+    int segments, int64_t seg_len, float multiplier, int mode, const float* __restrict__ g_coords,
+    const float* __restrict__ g_probs, const double* __restrict__ partial, float* __restrict__ g_volumes) {
+    const int64_t vol = blockIdx.x / segments;
+    const int seg = blockIdx.x % segments;
+    const int64_t frame = vol / n_volumes;
+    const float* p = probs + vol * N;
+    const float* gp = g_probs != nullptr ? g_probs + vol * N : nullptr;
+    const float* xyz = coords != nullptr ? coords + frame * N * 3 : nullptr;
+    float* gx = g_volumes + vol * N;
+    double gc[3] = {0.0, 0.0, 0.0};
+    if (g_coords != nullptr) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gc[a] = g_coords[vol * 3 + a];
+    }
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (mode != 1) {  // the segments' partial sums, added in segment order by every thread alike
+        for (int k = 0; k < segments; ++k) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s[a] += partial[(vol * segments + k) * 4 + a];
         }
     }
+    const double m = static_cast<double>(multiplier);
+    const double dot = s[0], mass = s[0];
+    const double c[3] = {s[1] / mass, s[2] / mass, s[3] / mass};
+    const int64_t i0 = seg * seg_len, i1 = (i0 + seg_len < N) ? i0 + seg_len : N;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kVolumeThreads) {
+        double x[3];
+        voxel_xyz(xyz, i, vy, vz, x);
+        const double gpi = gp != nullptr ? static_cast<double>(gp[i]) : 0.0;
+        const float pi = p[i];
+        if (mode == 0) {
+            const double G = gpi + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
+            gx[i] = static_cast<float>(m * static_cast<double>(pi) * (G - dot));
+        } else if (mode == 1) {
+            const double G = gpi + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
+            gx[i] = pi > 0.0f ? static_cast<float>(m * G) : 0.0f;
+        } else {
+            const double G = gpi + (gc[0] * (x[0] - c[0]) + gc[1] * (x[1] - c[1]) + gc[2] * (x[2] - c[2])) / mass;
+            gx[i] = pi > 0.0f ? static_cast<float>(m * G) : 0.0f;
+        }
+    }
+}
+
+// Segments per volume: enough workgroups for the chip, segments of at least 4096 voxels.
+inline int volume_segments(int64_t count, int64_t N) {
+    int64_t s = (2048 + count - 1) / count;
+    const int64_t by_size = (N + 4095) / 4096;
+    if (s > by_size) s = by_size;
+    if (s > kMaxSegments) s = kMaxSegments;
+    return s < 1 ? 1 : static_cast<int>(s);
+}
+
+bool slices_fit(int h, int w, int n_views) {
+    return static_cast<size_t>(h) * slice_row(w) * sizeof(double) <= kMapsMaxSliceBytes && n_views <= kMapsMaxViews &&
+           !(kernel_selection() & MVX_SELECT_NO_BACKWARD_IN_LDS);
 }
 
 }  // namespace
 
 }  // namespace mvx
 
+extern "C" size_t mvx_unproject_backward_workspace_bytes(int64_t n_frames, int n_views, int n_channels, int h, int w,
+                                                         int vx, int vy, int vz, int aggregation) {
+    if (n_frames <= 0 || n_views <= 0 || n_channels <= 0 || h <= 0 || w <= 0 || vx <= 0 || vy <= 0 || vz <= 0) return 0;
+    if (aggregation != MVX_AGG_MAX && aggregation != MVX_AGG_SOFTMAX) return 0;
+    if (!mvx::slices_fit(h, w, n_views)) return 0;
+    const size_t pairs = static_cast<size_t>((n_channels + 3) / 4 * 2);
+    const size_t per_pair_voxel = aggregation == MVX_AGG_SOFTMAX ? 16 : 8;
+    return static_cast<size_t>(n_frames) * pairs * vx * vy * vz * per_pair_voxel;
+}
+
 extern "C" int mvx_unproject_backward(const float* features_cl, const float* proj, const float* coords,
                                       const float* vol_conf, const float* grad_volumes, int64_t n_frames, int n_views,
                                       int n_channels, int h, int w, int vx, int vy, int vz, int aggregation,
-                                      float* grad_features_cl, float* grad_vol_conf, void* stream) {
+                                      float* grad_features_cl, float* grad_vol_conf, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
     using namespace mvx;
     const char* name = "mvx_unproject_backward";
     MVX_REQUIRE(n_frames >= 0 && n_views > 0 && n_channels > 0 && h >= 2 && w >= 2 && vx >= 0 && vy >= 0 && vz >= 0,
@@ -282,10 +535,13 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
     MVX_REQUIRE(grad_features_cl != nullptr && aligned16(grad_features_cl), MVX_ERR_INVALID_ARGUMENT,
                 "%s: grad_features_cl must be a 16-byte aligned device pointer", name);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(grad_features_cl, 0, static_cast<size_t>(n_frames) * V * map * sizeof(float), st);
-    if (e == hipSuccess && grad_vol_conf != nullptr)
-        e = hipMemsetAsync(grad_vol_conf, 0, static_cast<size_t>(n_frames) * V * C * sizeof(float), st);
-    MVX_REQUIRE(e == hipSuccess, MVX_ERR_HIP, "%s: clearing the gradients failed: %s", name, hipGetErrorString(e));
+    const bool in_lds = slices_fit(h, w, V) && n_voxels > 0 && n_frames * V * (Cp / 2) <= 0x7fffffffLL;
+    if (!in_lds) {  // the any-shape kernel adds into gradients that start at zero (and an empty grid leaves them zero)
+        hipError_t e = hipMemsetAsync(grad_features_cl, 0, static_cast<size_t>(n_frames) * V * map * sizeof(float), st);
+        if (e == hipSuccess && grad_vol_conf != nullptr)
+            e = hipMemsetAsync(grad_vol_conf, 0, static_cast<size_t>(n_frames) * V * C * sizeof(float), st);
+        MVX_REQUIRE(e == hipSuccess, MVX_ERR_HIP, "%s: clearing the gradients failed: %s", name, hipGetErrorString(e));
+    }
     if (n_voxels == 0) return MVX_OK;
     const bool needs_maps = aggregation == MVX_AGG_MAX || aggregation == MVX_AGG_SOFTMAX ||
                             (aggregation == MVX_AGG_CONF && grad_vol_conf != nullptr);
@@ -296,11 +552,66 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
     MVX_REQUIRE(aggregation != MVX_AGG_CONF || vol_conf != nullptr, MVX_ERR_INVALID_ARGUMENT,
                 "%s: confidence aggregation needs vol_conf", name);
     MVX_REQUIRE(map < (1ULL << 30), MVX_ERR_UNSUPPORTED, "%s: one feature map exceeds 2^30 elements (4 GB)", name);
+    MVX_REQUIRE(n_frames < (1LL << 31), MVX_ERR_UNSUPPORTED, "%s: too many frames", name);
     const double sx = static_cast<double>(w - 1) / static_cast<double>(h);
     const double sy = static_cast<double>(h - 1) / static_cast<double>(w);
-    MVX_REQUIRE(n_frames < (1LL << 31), MVX_ERR_UNSUPPORTED, "%s: too many frames", name);
-    // rounds of frames, so that a launch stays below 2^31 workgroups
+    // rounds of frames, so that a one-lane-per-voxel launch stays below 2^31 workgroups
     const int64_t per_round = n_voxels >= (1LL << 38) ? 1 : (1LL << 38) / n_voxels;
+    if (in_lds) {
+        const bool with_stats = aggregation == MVX_AGG_MAX || aggregation == MVX_AGG_SOFTMAX;
+        float* stats = nullptr;
+        if (with_stats) {
+            const size_t need = mvx_unproject_backward_workspace_bytes(n_frames, V, C, h, w, vx, vy, vz, aggregation);
+            MVX_REQUIRE(workspace != nullptr && workspace_bytes >= need, MVX_ERR_WORKSPACE,
+                        "%s: workspace of %zu bytes is too small (%zu needed)", name, workspace_bytes, need);
+            MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", name);
+            stats = static_cast<float*>(workspace);
+            const size_t per_frame = need / static_cast<size_t>(n_frames) / sizeof(float);
+            for (int64_t f0 = 0; f0 < n_frames; f0 += per_round) {
+                const int64_t nf = (n_frames - f0 < per_round) ? n_frames - f0 : per_round;
+                const int64_t n_total = nf * n_voxels;
+                const int64_t blocks = (n_total + kBackwardThreads - 1) / kBackwardThreads;
+                MVX_REQUIRE(blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
+                VoxelSource cd{};
+                cd.volume = coords + f0 * n_voxels * 3;
+                cd.first_frame = f0;
+                cd.vy = vy;
+                cd.vz = vz;
+                if (aggregation == MVX_AGG_MAX)
+                    hipLaunchKernelGGL(unproject_view_stats<MVX_AGG_MAX>, dim3(static_cast<unsigned>(blocks)),
+                                       dim3(kBackwardThreads), 0, st, features_cl + f0 * V * map, proj + f0 * V * 12, cd,
+                                       n_total, V, Cp, h, w, n_voxels, sx, sy, stats + f0 * per_frame);
+                else
+                    hipLaunchKernelGGL(unproject_view_stats<MVX_AGG_SOFTMAX>, dim3(static_cast<unsigned>(blocks)),
+                                       dim3(kBackwardThreads), 0, st, features_cl + f0 * V * map, proj + f0 * V * 12, cd,
+                                       n_total, V, Cp, h, w, n_voxels, sx, sy, stats + f0 * per_frame);
+                MVX_CHECK_LAUNCH("mvx_unproject_backward (view statistics)");
+            }
+        }
+        VoxelSource cd{};
+        cd.volume = coords;
+        cd.vy = vy;
+        cd.vz = vz;
+        const size_t lds = static_cast<size_t>(h) * slice_row(w) * sizeof(double);
+        const dim3 grid(static_cast<unsigned>(n_frames * V * (Cp / 2)));
+#define MVX_LAUNCH_BACKWARD_MAPS(AGG)                                                                                  \
+    do {                                                                                                               \
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(unproject_backward_maps<AGG>),               \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));        \
+        MVX_REQUIRE(ea == hipSuccess, MVX_ERR_HIP, "%s: %zu bytes of LDS refused: %s", name, lds, hipGetErrorString(ea)); \
+        hipLaunchKernelGGL(unproject_backward_maps<AGG>, grid, dim3(kMapsThreads), lds, st, features_cl, proj, cd, vol_conf, \
+                           grad_volumes, stats, V, C, Cp, h, w, n_voxels, sx, sy, grad_features_cl, grad_vol_conf);    \
+    } while (0)
+        switch (aggregation) {
+            case MVX_AGG_SUM: MVX_LAUNCH_BACKWARD_MAPS(MVX_AGG_SUM); break;
+            case MVX_AGG_CONF: MVX_LAUNCH_BACKWARD_MAPS(MVX_AGG_CONF); break;
+            case MVX_AGG_MAX: MVX_LAUNCH_BACKWARD_MAPS(MVX_AGG_MAX); break;
+            default: MVX_LAUNCH_BACKWARD_MAPS(MVX_AGG_SOFTMAX); break;
+        }
+#undef MVX_LAUNCH_BACKWARD_MAPS
+        MVX_CHECK_LAUNCH(name);
+        return MVX_OK;
+    }
     for (int64_t f0 = 0; f0 < n_frames; f0 += per_round) {
         const int64_t nf = (n_frames - f0 < per_round) ? n_frames - f0 : per_round;
         const int64_t n_total = nf * n_voxels;
@@ -330,10 +641,15 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
     return MVX_OK;
 }
 
+extern "C" size_t mvx_soft_argmax_3d_backward_workspace_bytes(int64_t n_frames, int n_volumes, int sx, int sy, int sz) {
+    if (n_frames <= 0 || n_volumes <= 0 || sx <= 0 || sy <= 0 || sz <= 0) return 0;
+    return static_cast<size_t>(n_frames) * n_volumes * mvx::kMaxSegments * 4 * sizeof(double);
+}
+
 extern "C" int mvx_soft_argmax_3d_backward(const float* volumes_out, const float* coords, int64_t n_frames,
                                            int n_volumes, int sx, int sy, int sz, float multiplier, int softmax,
                                            const float* grad_coordinates, const float* grad_volumes_out,
-                                           float* grad_volumes, void* stream) {
+                                           float* grad_volumes, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace mvx;
     const char* name = "mvx_soft_argmax_3d_backward";
     MVX_REQUIRE(n_frames >= 0 && n_volumes >= 0 && sx > 0 && sy > 0 && sz > 0, MVX_ERR_INVALID_ARGUMENT,
@@ -342,13 +658,28 @@ extern "C" int mvx_soft_argmax_3d_backward(const float* volumes_out, const float
     if (count == 0) return MVX_OK;
     MVX_REQUIRE(volumes_out != nullptr && grad_volumes != nullptr, MVX_ERR_INVALID_ARGUMENT, "%s: null pointer argument",
                 name);
-    MVX_REQUIRE(count <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: too many volumes", name);
     const int64_t N = static_cast<int64_t>(sx) * sy * sz;
+    const int segments = volume_segments(count, N);
+    MVX_REQUIRE(count * segments <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: too many volumes", name);
     // the reference divides by the mass only in index space (mvn/utils/op.py:73-76)
     const int mode = softmax ? 0 : (coords != nullptr ? 1 : 2);
-    hipLaunchKernelGGL(soft_argmax_3d_backward, dim3(static_cast<unsigned>(count)), dim3(kVolumeThreads), 0,
-                       static_cast<hipStream_t>(stream), volumes_out, coords, n_volumes, sy, sz, N, multiplier, mode,
-                       grad_coordinates, grad_volumes_out, grad_volumes);
+    const int64_t seg_len = (N + segments - 1) / segments;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(static_cast<unsigned>(count * segments));
+    double* partial = static_cast<double*>(workspace);
+    if (mode != 1) {
+        MVX_REQUIRE(workspace != nullptr &&
+                        workspace_bytes >= mvx_soft_argmax_3d_backward_workspace_bytes(n_frames, n_volumes, sx, sy, sz),
+                    MVX_ERR_WORKSPACE, "%s: workspace of %zu bytes is too small", name, workspace_bytes);
+        MVX_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, MVX_ERR_INVALID_ARGUMENT,
+                    "%s: workspace must be 8-byte aligned", name);
+        hipLaunchKernelGGL(soft_argmax_3d_backward_sums, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords, n_volumes,
+                           sy, sz, N, segments, seg_len, mode, grad_coordinates, grad_volumes_out, partial);
+        MVX_CHECK_LAUNCH("mvx_soft_argmax_3d_backward (sums)");
+    }
+    hipLaunchKernelGGL(soft_argmax_3d_backward_write, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords, n_volumes, sy,
+                       sz, N, segments, seg_len, multiplier, mode, grad_coordinates, grad_volumes_out, partial,
+                       grad_volumes);
     MVX_CHECK_LAUNCH(name);
     return MVX_OK;
 }

@@ -104,10 +104,13 @@ class _SoftArgmax3D(torch.autograd.Function):
         gc = _cabi.device_f32(grad_coords, "grad_coords") if grad_coords is not None else None
         go = _cabi.device_f32(grad_out, "grad_out") if grad_out is not None else None
         grad = torch.empty_like(out)
+        lib = _cabi.load()
+        ws = torch.empty(max(lib.mvx_soft_argmax_3d_backward_workspace_bytes(b, n, sx, sy, sz), 8) // 8,
+                         dtype=torch.float64, device=out.device)
         with torch.cuda.device(out.device):
-            st = _cabi.load().mvx_soft_argmax_3d_backward(
+            st = lib.mvx_soft_argmax_3d_backward(
                 _cabi.ptr(out), _cabi.ptr(cv), b, n, sx, sy, sz, float(ctx.multiplier), int(ctx.softmax), _cabi.ptr(gc),
-                _cabi.ptr(go), _cabi.ptr(grad), _cabi.stream(out.device))
+                _cabi.ptr(go), _cabi.ptr(grad), _cabi.ptr(ws), ws.numel() * 8, _cabi.stream(out.device))
         _cabi.check(st, "mvx_soft_argmax_3d_backward")
         return grad, None, None, None
 
@@ -250,10 +253,14 @@ class _Unproject(torch.autograd.Function):
         grad_cl = torch.empty((b, v, h, w, cp), dtype=torch.float32, device=dev)
         grad_conf = torch.empty((b, v, c), dtype=torch.float32, device=dev) if want_conf else None
         vshape = tuple(cv.shape[1:4])
+        lib = _cabi.load()
+        ws_bytes = lib.mvx_unproject_backward_workspace_bytes(b, v, c, h, w, vshape[0], vshape[1], vshape[2], agg)
+        ws = torch.empty((ws_bytes + 15) // 16 * 4, dtype=torch.float32, device=dev) if ws_bytes else None
         with torch.cuda.device(dev):
-            st = _cabi.load().mvx_unproject_backward(
+            st = lib.mvx_unproject_backward(
                 _cabi.ptr(feats_cl), _cabi.ptr(proj), _cabi.ptr(cv), _cabi.ptr(vc), _cabi.ptr(grad), b, v, c, h, w,
-                vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(grad_cl), _cabi.ptr(grad_conf), _cabi.stream(dev))
+                vshape[0], vshape[1], vshape[2], agg, _cabi.ptr(grad_cl), _cabi.ptr(grad_conf), _cabi.ptr(ws),
+                ws.numel() * 4 if ws is not None else 0, _cabi.stream(dev))
         _cabi.check(st, "mvx_unproject_backward")
         # logical (batch, views, channels, h, w) over the channel-last memory the kernel wrote
         grad_maps = grad_cl[..., :c].permute(0, 1, 4, 2, 3) if ctx.needs_input_grad[0] else None

@@ -32,6 +32,15 @@ def load(name):
     return np.load(os.path.join(gc.GOLDEN_DIR, name + ".npz"))
 
 
+@pytest.fixture(params=["slices in LDS", "global atomics"])
+def backward_kernel(request):
+    """Runs a test once with each of the two unprojection backward kernels."""
+    lib = _cabi.load()
+    lib.mvx_set_kernel_selection(_cabi.SELECT_NO_BACKWARD_IN_LDS if request.param == "global atomics" else 0)
+    yield request.param
+    lib.mvx_set_kernel_selection(0)
+
+
 def small_case():
     case = gc.small_volumetric_inputs()
     up = gc.gradient_upstreams()
@@ -39,7 +48,7 @@ def small_case():
 
 
 @pytest.mark.parametrize("method", gc.UNPROJECT_METHODS)
-def test_unproject_gradients_match_the_reference_autograd(method):
+def test_unproject_gradients_match_the_reference_autograd(method, backward_kernel):
     (feats, proj, coord, vconf, _), up = small_case()
     g = load("grads")
     f, c = t(feats, True), t(vconf, True)
@@ -114,7 +123,7 @@ def test_soft_argmax_3d_gradients_match_the_reference_autograd(softmax, with_coo
 
 @pytest.mark.parametrize("views", [2, 3, 4])
 @pytest.mark.parametrize("method", ["sum", "conf", "max", "softmax"])
-def test_unproject_gradients_model_shapes(views, method):
+def test_unproject_gradients_model_shapes(views, method, backward_kernel):
     """32 channels, 96 x 96 maps, a 16^3 grid (coarse enough for the numpy oracle), maps in both layouts, against
     the float64 oracle."""
     case = synth.volumetric_case(4200 + views, 2, views, volume_size=16, with_volumes=False)
@@ -145,6 +154,17 @@ def test_unproject_gradients_model_shapes(views, method):
     (vol * t(up).double()).sum().backward()
     assert f64.grad.dtype == torch.float64
     assert np.abs(f64.grad.cpu().numpy() - o_maps).max() <= 1e-5 * scale
+
+
+def test_unproject_gradients_of_maps_too_large_for_lds():
+    """112 x 112 maps (12 544 pixels: no 4-channel slice fits 160 KB of LDS) go through the global-atomics kernel."""
+    case = synth.volumetric_case(4400, 1, 3, n_channels=8, volume_size=16, heatmap_size=112, with_volumes=False)
+    feats, proj, coord = (case[k] for k in ("features", "proj", "coord_volumes"))
+    up = np.random.default_rng(5).standard_normal((1, 8, 16, 16, 16)).astype(np.float32)
+    f = t(feats, True)
+    (op.unproject_heatmaps(f, t(proj), t(coord), "softmax") * t(up)).sum().backward()
+    want, _ = orc.unproject_heatmaps_backward(feats, proj, coord, up, "softmax")
+    assert np.abs(f.grad.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
 
 
 def test_unproject_gradient_is_linear_and_deterministic_enough():
