@@ -344,6 +344,114 @@ def run_volumetric(args, dev, rank, world, frames=64):
     return ms, frames, roof, cfg, extra
 
 
+def cpu_baseline_training(sample_frames):
+    """Forward + backward of the two volumetric ops in the torch-CPU port (autograd through grid_sample, softmax and
+    einsum, the reference's formulation) on a bounded sample, host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_port
+    threads = torch.get_num_threads()
+    case = synth.volumetric_case(1234 + 5, sample_frames, 4)
+    f, p, c, vc, vol = (torch.from_numpy(case[k]) for k in ("features", "proj", "coord_volumes", "vol_confidences", "volumes"))
+    up_u = torch.randn(sample_frames, 32, 64, 64, 64)
+    up_k, up_p = torch.randn(sample_frames, 17, 3), torch.randn_like(vol)
+    ts = []
+    for i in range(2):
+        t0 = time.perf_counter()
+        fg = f.clone().requires_grad_(True)
+        torch_port.unproject(fg, p, c, "softmax", vc).backward(up_u)
+        vg = vol.clone().requires_grad_(True)
+        torch.autograd.backward(list(torch_port.soft_argmax_3d_coords(vg, c)), [up_k, up_p])
+        if i >= 1:
+            ts.append(time.perf_counter() - t0)
+    secs = float(np.median(ts))
+    return {"value": sample_frames / secs, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frame(s), forward + backward of unproject (softmax) and 3-D soft-argmax, second of 2 passes" % sample_frames}
+
+
+def run_training(args, dev, rank, world, frames=8):
+    """Forward + backward of the two volumetric ops as a training step of VolumetricTriangulationNet runs them
+    (train.py:281-290; a batch of a few frames): gradients of the unprojected volumes flow to the feature maps, those
+    of the keypoints and of the normalised volumes to the volume net's output."""
+    case = synth.device_volumetric_case(1234 + 5 + rank, frames, 4, dev)
+    feats, proj, vconf, vols = (case[k] for k in ("features", "proj", "vol_confidences", "volumes"))
+    coord = library_grid(torch.from_numpy(case["base_points"]), dev)
+    b, v, c, h, w = feats.shape
+    fcl = feats.view(b * v, c, h, w).contiguous(memory_format=torch.channels_last).view(b, v, c, h, w)
+    gen = torch.Generator(device=dev).manual_seed(77 + rank)
+    up_u = torch.randn((frames, 32, 64, 64, 64), device=dev, generator=gen)
+    up_k = torch.randn((frames, 17, 3), device=dev, generator=gen)
+    up_p = torch.randn(vols.shape, device=dev, generator=gen)
+    timers = {k: EventTimer() for k in ("unproject_forward", "unproject_backward", "soft_argmax_3d_forward",
+                                        "soft_argmax_3d_backward")}
+    sg = StepGather((frames, 17, 3), dev, world)
+    grads = {}
+
+    def step(timed):
+        dst = sg.buffer()
+        f = fcl.detach().requires_grad_(True)
+        x = vols.detach().requires_grad_(True)
+        if timed:
+            with timers["unproject_forward"]:
+                u = op.unproject_heatmaps(f, proj, coord, "softmax", vconf)
+            with timers["unproject_backward"]:
+                u.backward(up_u)
+            with timers["soft_argmax_3d_forward"]:
+                kp, prob = op.integrate_tensor_3d_with_coordinates(x, coord, True)
+            with timers["soft_argmax_3d_backward"]:
+                torch.autograd.backward([kp, prob], [up_k, up_p])
+        else:
+            u = op.unproject_heatmaps(f, proj, coord, "softmax", vconf)
+            u.backward(up_u)
+            kp, prob = op.integrate_tensor_3d_with_coordinates(x, coord, True)
+            torch.autograd.backward([kp, prob], [up_k, up_p])
+        grads["maps"], grads["volumes"] = f.grad, x.grad
+        dst.copy_(kp.detach())
+        sg.submit()
+
+    # sanity before timing: with an upstream gradient that is zero outside a few voxels of one frame, the map gradient
+    # is what autograd gives through the float64 torch evaluation of those voxels; the volume gradient of one frame
+    # against float64 torch
+    frame = frames // 2
+    voxels = torch.arange(0, 64 ** 3, 997, device=dev)
+    sparse = torch.zeros_like(up_u)
+    sparse[frame].view(32, -1)[:, voxels] = up_u[frame].view(32, -1)[:, voxels]
+    f = fcl.detach().requires_grad_(True)
+    op.unproject_heatmaps(f, proj, coord, "softmax", vconf).backward(sparse)
+    f64 = feats.double().requires_grad_(True)
+    (torch_unproject_softmax(f64, proj, coord, frame, voxels) * up_u[frame].view(32, -1)[:, voxels].double()).sum().backward()
+    scale = float(f64.grad.abs().max())
+    err_maps = float((f.grad.double() - f64.grad).abs().max()) / scale
+    assert err_maps < 1e-5, "map gradients are %g (relative) from float64 autograd" % err_maps
+    x64 = vols[frame].double().requires_grad_(True)
+    p64 = torch.softmax(x64.reshape(17, -1), dim=1)
+    k64 = (p64.unsqueeze(-1) * coord[frame].reshape(1, -1, 3).double()).sum(1)
+    ((k64 * up_k[frame].double()).sum() + (p64 * up_p[frame].reshape(17, -1).double()).sum()).backward()
+    step(False)
+    err_vol = float((grads["volumes"][frame].double() - x64.grad).abs().max() / x64.grad.abs().max())
+    assert err_vol < 1e-5, "volume gradients are %g (relative) from float64 autograd" % err_vol
+
+    ms = timed_loop(step, args, dev, world, sg)
+    n_vox = 64 ** 3
+    tb = timers["unproject_backward"].mean_ms()
+    # what the backward has to move: the upstream gradient and the coordinates in, the map gradients out (the view
+    # statistics it writes and reads back, 16 B per channel pair and voxel, are its own device)
+    moved = frames * (32 * n_vox * 4 + n_vox * 12 + 2 * 4 * 32 * 96 * 96 * 4)
+    roof = {"bound": "hbm", "kernel": "unproject_view_stats<softmax> + unproject_backward_maps<softmax>",
+            "achieved": moved / (tb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "traffic_source": "not collected", "algorithmic_bytes_per_launch": moved, "avg_launch_ms": tb,
+            "note": "bound by LDS atomic additions (float64, 4-7 lanes per clock per CU) and by re-sampling the maps, not "
+                    "by HBM: the fraction is reported for completeness"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    extra = {k + "_ms": t.mean_ms() for k, t in timers.items()}
+    extra["timers_note"] = "HIP events around the op call and around autograd's backward call (kernels plus the Python around them)"
+    extra["map_gradient_relative_error_vs_float64_autograd"] = err_maps
+    extra["volume_gradient_relative_error_vs_float64_autograd"] = err_vol
+    cfg = {"workload": "training step of the volumetric ops: forward + backward of unproject (4 views x 32ch 96x96 -> 64^3, "
+                       "softmax) and of the 3-D soft-argmax of 17 volumes, %d frames/GPU" % frames,
+           "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world}
+    return ms, frames, roof, cfg, extra
+
+
 def run_sharded(args, dev, rank, world, total=65536, alg_block=4096, vol_block=64):
     """BASELINE configs[3]: `total` frames in contiguous shards over the ranks, algebraic then volumetric leg per
     frame, one all-gather of both keypoint sets.  The shard is streamed through resident input blocks (4096 frames
@@ -793,6 +901,7 @@ METRICS = {
     "ransac": "RANSAC-triangulated frames/sec (4-view, 17-joint)",
     "stream16": "triangulated frames/sec (16-view, 17-joint)",
     "sharded": "triangulated frames/sec (4-view, 17-joint; algebraic + volumetric leg per frame, 65536 frames sharded)",
+    "training": "volumetric frames/sec, forward + backward of unproject and 3-D soft-argmax (4-view, 64^3, 17 joints)",
 }
 
 
@@ -805,6 +914,8 @@ def cpu_baseline_for(name, small=False):
         return cpu_baseline_ransac(16)
     if name == "stream16":
         return cpu_baseline_algebraic(16, 64)
+    if name == "training":
+        return cpu_baseline_training(1)
     if name == "sharded":
         # per frame the path runs both legs: frames/s = 1 / (1/algebraic + 1/volumetric)
         a = cpu_baseline_algebraic(4, 64 if small else 256)
@@ -831,6 +942,8 @@ def run_workload(name, args, dev, rank, world):
         extra["all_view_pairs"] = {"value": frames_all * world / (ms_all * 1e-3), "unit": "frames/s", "ms_per_step": ms_all,
                                    "ransac_kernel_and_casts_ms": extra_all["ransac_kernel_and_casts_ms"],
                                    "note": "every pair instead of the reference's ten sampled ones: no host work"}
+    elif name == "training":
+        ms, frames, roof, cfg, extra = run_training(args, dev, rank, world, args.frames or 8)
     elif name == "sharded":
         total = args.frames or 65536
         ms, frames, roof, cfg, extra = run_sharded(args, dev, rank, world, total)

@@ -19,8 +19,11 @@
 //   unproject_view_stats     max and softmax only, before the kernel above: what those aggregations need of ALL views
 //                            at a voxel -- the index of the first maximal view, or log-sum-exp and the aggregated
 //                            value -- written once per (channel pair, voxel) into the workspace, so that each slice
-//                            samples its own view only (without it: 16 x 4 slices each sample 4 views, 8.2 ms for
-//                            8 frames instead of 2).
+//                            samples its own view only (without it the 16 x 4 slices of a frame each sample 4 views:
+//                            8.2 ms for 8 frames of the model's shape instead of 3.2).
+// Measured on one MI355X, 8 frames x 4 views x 32 channels x 96 x 96 -> 64^3, kernels alone: sum 0.79 ms, max 1.3,
+// confidences with their gradient 2.3, softmax 3.2.  What is left is the re-sampling: a slice reads 8 bytes of each
+// 128-byte pixel, so the 16 slices of a view fetch every line 16 times through the texture path.
 //   unproject_backward       any shape: one lane per voxel, float32 atomic adds at agent scope into a gradient the
 //                            entry point has zeroed (for 8 frames of the model's shape 52 ms: every addition is a
 //                            round trip to the memory side, and their order is not fixed: two runs differ in the last
