@@ -232,8 +232,10 @@ int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, 
  * grad_vol_conf     [n_frames][n_views][n_channels]   out, MVX_AGG_CONF only (sum over the voxels of gradient x
  *                                                     sample); written by the call; may be NULL
  * workspace         mvx_unproject_backward_workspace_bytes() bytes of device memory, 16-byte aligned: for MVX_AGG_MAX
- *                   and MVX_AGG_SOFTMAX, what the aggregation needs of all views at a voxel (first maximal view;
- *                   log-sum-exp and aggregate), 8 or 16 bytes per (channel pair, voxel); 0 bytes otherwise (NULL allowed)
+ *                   and MVX_AGG_SOFTMAX, the derivative of the aggregate with respect to each view's sample, one float
+ *                   per (view, channel, voxel) -- the size of the per-view volumes of the reference, 134 MB per frame
+ *                   for 4 views x 32 channels x 64^3; for MVX_AGG_CONF the partial sums behind grad_vol_conf (about
+ *                   1 KB per frame, view and 2048 voxels); 0 bytes for MVX_AGG_SUM (NULL allowed)
  * Maps of up to about 9 600 pixels (96 x 96 fits) and up to 16 views accumulate slices of the gradient in LDS, in
  * float64, and are written once (no atomics in global memory; two runs agree except for float64 rounding before the
  * final conversion); other shapes use float32 atomic additions in global memory in no fixed order.

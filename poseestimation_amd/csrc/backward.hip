@@ -16,14 +16,16 @@
 //                            Rows of the slice are padded by one element: the voxels of a wave lie along one grid
 //                            axis and project onto a line of pixels, and with rows of 2 W doubles a vertical line
 //                            would fall into one pair of LDS banks.
-//   unproject_view_stats     max and softmax only, before the kernel above: what those aggregations need of ALL views
-//                            at a voxel -- the index of the first maximal view, or log-sum-exp and the aggregated
-//                            value -- written once per (channel pair, voxel) into the workspace, so that each slice
-//                            samples its own view only (without it the 16 x 4 slices of a frame each sample 4 views:
-//                            8.2 ms for 8 frames of the model's shape instead of 3.2).
-// Measured on one MI355X, 8 frames x 4 views x 32 channels x 96 x 96 -> 64^3, kernels alone: sum 0.79 ms, max 1.3,
-// confidences with their gradient 2.3, softmax 3.2.  What is left is the re-sampling: a slice reads 8 bytes of each
-// 128-byte pixel, so the 16 slices of a view fetch every line 16 times through the texture path.
+//   unproject_view_factors   max and softmax only, before the kernel above: the derivative of the aggregate with
+//                            respect to each view's sample, written once per (view, channel, voxel) into the workspace
+//                            (the size of the per-view volumes the forward never materialises: V C N floats per frame,
+//                            134 MB for the model's shape), so that the slices sample nothing.  Each of the 16 slices
+//                            of a view sampling for itself uses 8 of the 128 bytes of every pixel it touches, and the
+//                            texture path handles one line per lane whatever it returns: softmax for 8 frames 8.2 ms
+//                            with every slice sampling all views, 3.2 ms with per-voxel statistics and its own view.
+//   unproject_confidence_sums  confidence aggregation with the confidences' gradient wanted, before the slice kernel:
+//                            sum over voxels of gradient x sample per (view, channel), in runs of 2048 voxels whose
+//                            totals the slice kernel adds up in order.
 //   unproject_backward       any shape: one lane per voxel, float32 atomic adds at agent scope into a gradient the
 //                            entry point has zeroed (for 8 frames of the model's shape 52 ms: every addition is a
 //                            round trip to the memory side, and their order is not fixed: two runs differ in the last
@@ -190,103 +192,141 @@ constexpr size_t kMapsMaxSliceBytes = 152 * 1024;
 
 __host__ __device__ inline int slice_row(int W) { return 2 * W + 1; }  // doubles per padded row of a slice
 
-// Per (frame, channel pair, voxel), for the slices of the kernel below.  softmax: float4 {L0, out0, L1, out1} with
-// L = log sum_u exp(x_u) and out = sum_u softmax(x)_u x_u of the pair's two channels; max: float2 with the index of
-// the first view that holds the maximum.  One lane per voxel, the channels four quads at a time.
+// For max and softmax, before the slice kernel: the derivative of the aggregate with respect to every view's
+// sample, factors[frame][view][channel pair][voxel] (float2) -- 1 for the first view that holds the maximum and 0 for
+// the others (max), s_v (1 + x_v - out) with s the softmax over the views' samples x (softmax: out = sum_v s_v x_v).
+// One lane per (voxel, channel quad), consecutive lanes the quads of one voxel, so that 8 lanes read one whole
+// 128-byte pixel (for 32 channels) and the texture path serves a tap of 8 voxels per instruction rather than of one.
+// The views are sampled twice (the second time out of L1): the number of views is not known at compile time.
 template <int AGG>
-__global__ __launch_bounds__(kBackwardThreads) void unproject_view_stats(
-    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, int64_t n_total, int V, int Cp,
-    int H, int W, int64_t n_vox, double sx, double sy, float* __restrict__ stats) {
-    __shared__ double cam[kMapsMaxViews * 12];
+__global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
+    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, int64_t n_items, int V, int Cp,
+    int H, int W, int64_t n_vox, double sx, double sy, float* __restrict__ factors) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBackwardThreads + threadIdx.x;
-    // a workgroup may straddle two frames: the cameras are then read per lane from global memory instead
-    const int64_t b_first = (static_cast<int64_t>(blockIdx.x) * kBackwardThreads) / n_vox;
-    const int64_t last = static_cast<int64_t>(blockIdx.x) * kBackwardThreads + kBackwardThreads - 1;
-    const bool one_frame = (last < n_total ? last : n_total - 1) / n_vox == b_first;
-    if (one_frame && threadIdx.x < V * 12)
-        cam[threadIdx.x] = camera_entry(proj + (b_first * V + threadIdx.x / 12) * 12, threadIdx.x % 12, sx, sy);
-    __syncthreads();
-    if (idx >= n_total) return;
-    const int64_t b = idx / n_vox, n = idx - b * n_vox;
+    if (idx >= n_items) return;
+    const int Cq = Cp / 4, pairs = Cp / 2;
+    const int q = static_cast<int>(idx % Cq);
+    const int64_t bn = idx / Cq;
+    const int64_t b = bn / n_vox, n = bn - b * n_vox;
     double X, Y, Z;
     voxel_position(coord, b, n_vox, n, X, Y, Z);
     const size_t map = static_cast<size_t>(H) * W * Cp;
-    const int Cq = Cp / 4, pairs = Cp / 2;
-    for (int q0 = 0; q0 < Cq; q0 += 4) {
-        float top[4][4], den[4][4], num[4][4];
-        int first[4][4];
+    float top[4], den[4], num[4];
+    int first[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+    for (int k = 0; k < 4; ++k) {
+        top[k] = -INFINITY;
+        den[k] = 0.0f;
+        num[k] = 0.0f;
+        first[k] = 0;
+    }
+    for (int u = 0; u < V; ++u) {
+        double Pd[12];
+        load_camera(proj, b * V + u, sx, sy, Pd);
+        const Tap t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
+        float val[4];
+        sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q, val);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                top[j][k] = -INFINITY;
-                den[j][k] = 0.0f;
-                num[j][k] = 0.0f;
-                first[j][k] = 0;
-            }
-        }
-        for (int u = 0; u < V; ++u) {
-            Tap t;
-            if (one_frame) {
-                t = project_tap(cam + u * 12, X, Y, Z, H, W, 1.0f);
-            } else {
-                double Pd[12];
-                load_camera(proj, b * V + u, sx, sy, Pd);
-                t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (q0 + j >= Cq) continue;  // uniform
-                float val[4];
-                sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q0 + j, val);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (AGG == MVX_AGG_MAX) {
-                        const bool up = (u == 0) || (val[k] > top[j][k]);  // strictly greater: the first maximal view stays
-                        first[j][k] = up ? u : first[j][k];
-                        top[j][k] = up ? val[k] : top[j][k];
-                    } else {  // running maximum; what is summed so far is rescaled when it moves
-                        const float dd = val[k] - top[j][k];
-                        const float r = exp_neg(-fabsf(dd));
-                        const bool up = dd > 0.0f;
-                        const float keep = up ? r : 1.0f, e = up ? 1.0f : r;
-                        den[j][k] = fmaf(den[j][k], keep, e);
-                        num[j][k] = fmaf(num[j][k], keep, e * val[k]);
-                        top[j][k] = up ? val[k] : top[j][k];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (q0 + j >= Cq) continue;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const size_t at = (static_cast<size_t>(b) * pairs + 2 * (q0 + j) + h) * n_vox + n;
-                if (AGG == MVX_AGG_MAX) {
-                    reinterpret_cast<float2*>(stats)[at] =
-                        make_float2(static_cast<float>(first[j][2 * h]), static_cast<float>(first[j][2 * h + 1]));
-                } else {
-                    reinterpret_cast<float4*>(stats)[at] =
-                        make_float4(top[j][2 * h] + logf(den[j][2 * h]), num[j][2 * h] / den[j][2 * h],
-                                    top[j][2 * h + 1] + logf(den[j][2 * h + 1]), num[j][2 * h + 1] / den[j][2 * h + 1]);
-                }
+        for (int k = 0; k < 4; ++k) {
+            if (AGG == MVX_AGG_MAX) {
+                const bool up = (u == 0) || (val[k] > top[k]);  // strictly greater: the first maximal view stays
+                first[k] = up ? u : first[k];
+                top[k] = up ? val[k] : top[k];
+            } else {  // running maximum; what is summed so far is rescaled when it moves
+                const float dd = val[k] - top[k];
+                const float r = exp_neg(-fabsf(dd));
+                const bool up = dd > 0.0f;
+                const float keep = up ? r : 1.0f, e = up ? 1.0f : r;
+                den[k] = fmaf(den[k], keep, e);
+                num[k] = fmaf(num[k], keep, e * val[k]);
+                top[k] = up ? val[k] : top[k];
             }
         }
     }
+    float rden[4], out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        rden[k] = 1.0f / den[k];
+        out[k] = num[k] * rden[k];
+    }
+    for (int u = 0; u < V; ++u) {
+        float f[4];
+        if (AGG == MVX_AGG_MAX) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = first[k] == u ? 1.0f : 0.0f;
+        } else {
+            double Pd[12];
+            load_camera(proj, b * V + u, sx, sy, Pd);
+            const Tap t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
+            float val[4];
+            sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q, val);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = exp_neg(val[k] - top[k]) * rden[k] * (1.0f + val[k] - out[k]);
+        }
+        float2* row = reinterpret_cast<float2*>(factors) + ((static_cast<size_t>(b) * V + u) * pairs + 2 * q) * n_vox + n;
+        row[0] = make_float2(f[0], f[1]);
+        row[n_vox] = make_float2(f[2], f[3]);
+    }
+}
+
+// Confidence aggregation, before the slice kernel, when the gradient of the confidences is wanted:
+// sum over voxels of (gradient x this view's sample) per (view, channel), which is that gradient.  One workgroup per
+// (frame, run of kConfChunk voxels); lanes as in unproject_view_factors (8 lanes read one whole pixel).  A lane sums
+// its voxels of the run in a register view by view, the workgroup's lanes meet in LDS, and the run's totals go to
+// partial[frame][run][view][Cp] (float64) for the slice kernel to add up in run order.
+constexpr int kConfChunk = 2048;
+constexpr int kConfMaxChannels = 64;  // kMapsMaxViews x kConfMaxChannels doubles of LDS
+__global__ __launch_bounds__(kBackwardThreads) void unproject_confidence_sums(
+    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, const float* __restrict__ g_vol,
+    int runs, int V, int C, int Cp, int H, int W, int64_t n_vox, double sx, double sy, double* __restrict__ partial) {
+    __shared__ double acc[kMapsMaxViews * kConfMaxChannels];
+    const int tid = threadIdx.x;
+    const int Cq = Cp / 4;
+    const int64_t b = blockIdx.x / runs;
+    const int run = blockIdx.x % runs;
+    for (int i = tid; i < V * Cp; i += kBackwardThreads) acc[i] = 0.0;
+    __syncthreads();
+    const int q = tid % Cq;
+    const int lanes_per_voxel = Cq, voxels_per_round = kBackwardThreads / lanes_per_voxel;
+    const bool working = tid < voxels_per_round * lanes_per_voxel;
+    const int64_t n0 = static_cast<int64_t>(run) * kConfChunk;
+    const int64_t n1 = (n0 + kConfChunk < n_vox) ? n0 + kConfChunk : n_vox;
+    const size_t map = static_cast<size_t>(H) * W * Cp;
+    for (int u = 0; u < V; ++u) {
+        double Pd[12];
+        load_camera(proj, b * V + u, sx, sy, Pd);
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (working) {
+            for (int64_t n = n0 + tid / lanes_per_voxel; n < n1; n += voxels_per_round) {
+                double X, Y, Z;
+                voxel_position(coord, b, n_vox, n, X, Y, Z);
+                const Tap t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
+                float val[4];
+                sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q, val);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = (4 * q + k < C) ? g_vol[(b * C + 4 * q + k) * n_vox + n] : 0.0f;
+                    sum[k] = fmaf(g, val[k], sum[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(&acc[u * Cp + 4 * q + k], static_cast<double>(sum[k]));
+        }
+    }
+    __syncthreads();
+    double* out = partial + (static_cast<size_t>(b) * runs + run) * V * Cp;
+    for (int i = tid; i < V * Cp; i += kBackwardThreads) out[i] = acc[i];
 }
 
 // One workgroup per (frame, view, channel pair): the slice [h][w][2] of the gradient lives in LDS as float64, rows
-// padded to slice_row(W).  Dynamic LDS: H * slice_row(W) doubles.  Channels c0 = 4q + 2 * half and c0 + 1.
+// padded to slice_row(W).  Dynamic LDS: H * slice_row(W) doubles.  Channels c0 = 2 * pair and c0 + 1.
 template <int AGG>
 __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
-    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord,
-    const float* __restrict__ vconf, const float* __restrict__ g_vol, const float* __restrict__ stats, int V, int C,
-    int Cp, int H, int W, int64_t n_vox, double sx, double sy, float* __restrict__ g_feat_cl,
-    float* __restrict__ g_conf) {
+    const float* __restrict__ proj, VoxelSource coord, const float* __restrict__ vconf, const float* __restrict__ g_vol, const float* __restrict__ factors,
+    const double* __restrict__ conf_partial, int conf_runs, int V, int C, int Cp, int H, int W, int64_t n_vox, double sx,
+    double sy, float* __restrict__ g_feat_cl, float* __restrict__ g_conf) {
     extern __shared__ double slice[];
     __shared__ double cam[12];
-    __shared__ double sums[2 * (kMapsThreads / 64)];
     const int tid = threadIdx.x;
     const int pairs = Cp / 2;
     unsigned id = blockIdx.x;
@@ -294,13 +334,12 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
     id /= pairs;
     const int v = static_cast<int>(id % V);
     const int64_t b = id / V;
-    const int q = pair >> 1, half = pair & 1, c0 = 2 * pair;  // c0 + 1 may be padding
+    const int c0 = 2 * pair;  // c0 + 1 may be padding
     const int RS = slice_row(W);
     for (int i = tid; i < H * RS; i += kMapsThreads) slice[i] = 0.0;
     if (tid < 12) cam[tid] = camera_entry(proj + (b * V + v) * 12, tid, sx, sy);
     __syncthreads();
     const size_t map = static_cast<size_t>(H) * W * Cp;
-    const float* img = feat_cl + (b * V + v) * map;
     constexpr bool kNeedsValues = AGG == MVX_AGG_MAX || AGG == MVX_AGG_SOFTMAX;
     const bool wants_conf = AGG == MVX_AGG_CONF && g_conf != nullptr;
     float conf[2] = {0.0f, 0.0f};
@@ -308,7 +347,6 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
 #pragma unroll
         for (int k = 0; k < 2; ++k) conf[k] = (c0 + k < C) ? vconf[(b * V + v) * C + c0 + k] : 0.0f;
     }
-    double conf_grad[2] = {0.0, 0.0};
     for (int64_t n = tid; n < n_vox; n += kMapsThreads) {
         double X, Y, Z;
         voxel_position(coord, b, n_vox, n, X, Y, Z);
@@ -317,34 +355,13 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
         for (int k = 0; k < 2; ++k) g[k] = (c0 + k < C) ? g_vol[(b * C + c0 + k) * n_vox + n] : 0.0f;
         const TapXY t = project_tap_xy(cam, X, Y, Z, H, W, 1.0f);
         float d[2];
-        if (kNeedsValues || wants_conf) {
-            Tap tp;
-            tp.w00 = t.w00;
-            tp.w01 = t.w01;
-            tp.w10 = t.w10;
-            tp.w11 = t.w11;
-            tp.pixel = static_cast<unsigned>(t.yb * W + t.xb);
-            float quad[4];
-            sample_quad(img, tp, W, Cp, q, quad);
-            const float mine[2] = {half ? quad[2] : quad[0], half ? quad[3] : quad[1]};
-            if (AGG == MVX_AGG_MAX) {
-                const float2 first = reinterpret_cast<const float2*>(stats)[(static_cast<size_t>(b) * pairs + pair) * n_vox + n];
-                d[0] = static_cast<int>(first.x) == v ? g[0] : 0.0f;
-                d[1] = static_cast<int>(first.y) == v ? g[1] : 0.0f;
-            } else if (AGG == MVX_AGG_SOFTMAX) {
-                // out = sum_u s_u x_u with s = softmax(x):  d out / d x_v = s_v (1 + x_v - out),  s_v = exp(x_v - L)
-                const float4 st = reinterpret_cast<const float4*>(stats)[(static_cast<size_t>(b) * pairs + pair) * n_vox + n];
-                d[0] = g[0] * exp_neg(fminf(mine[0] - st.x, 0.0f)) * (1.0f + mine[0] - st.y);
-                d[1] = g[1] * exp_neg(fminf(mine[1] - st.z, 0.0f)) * (1.0f + mine[1] - st.w);
-            } else {
-                d[0] = g[0] * conf[0];
-                d[1] = g[1] * conf[1];
-                conf_grad[0] += static_cast<double>(g[0] * mine[0]);
-                conf_grad[1] += static_cast<double>(g[1] * mine[1]);
-            }
+        if (kNeedsValues) {  // the derivative of the aggregate with respect to this view's sample, from the pre-pass
+            const float2 f = reinterpret_cast<const float2*>(factors)[((static_cast<size_t>(b) * V + v) * pairs + pair) * n_vox + n];
+            d[0] = g[0] * f.x;
+            d[1] = g[1] * f.y;
         } else {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) d[k] = AGG == MVX_AGG_CONF ? g[k] * conf[k] : g[k];
+            d[0] = AGG == MVX_AGG_CONF ? g[0] * conf[0] : g[0];
+            d[1] = AGG == MVX_AGG_CONF ? g[1] * conf[1] : g[1];
         }
         double* p = slice + t.yb * RS + 2 * t.xb;
         const float w4[4] = {t.w00, t.w01, t.w10, t.w11};
@@ -363,19 +380,10 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
         const double* e = slice + y * RS + 2 * x;
         *reinterpret_cast<float2*>(out + static_cast<size_t>(i) * Cp) = make_float2(static_cast<float>(e[0]), static_cast<float>(e[1]));
     }
-    if (wants_conf) {
-        const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double sw = wave_sum(conf_grad[k]);
-            if (lane == 0) sums[k * (kMapsThreads / 64) + wave] = sw;
-        }
-        __syncthreads();
-        if (tid < 2 && c0 + tid < C) {
-            double total = 0.0;
-            for (int w = 0; w < kMapsThreads / 64; ++w) total += sums[tid * (kMapsThreads / 64) + w];
-            g_conf[(b * V + v) * C + c0 + tid] = static_cast<float>(total);
-        }
+    if (wants_conf && tid < 2 && c0 + tid < C) {  // the runs' sums of gradient x sample, added in run order
+        double total = 0.0;
+        for (int r = 0; r < conf_runs; ++r) total += conf_partial[((static_cast<size_t>(b) * conf_runs + r) * V + v) * Cp + c0 + tid];
+        g_conf[(b * V + v) * C + c0 + tid] = static_cast<float>(total);
     }
 }
 
@@ -500,8 +508,9 @@ inline int volume_segments(int64_t count, int64_t N) {
     return s < 1 ? 1 : static_cast<int>(s);
 }
 
-bool slices_fit(int h, int w, int n_views) {
+bool slices_fit(int h, int w, int n_views, int n_channels, int aggregation) {
     return static_cast<size_t>(h) * slice_row(w) * sizeof(double) <= kMapsMaxSliceBytes && n_views <= kMapsMaxViews &&
+           (aggregation != MVX_AGG_CONF || (n_channels + 3) / 4 * 4 <= kConfMaxChannels) &&
            !(kernel_selection() & MVX_SELECT_NO_BACKWARD_IN_LDS);
 }
 
@@ -512,11 +521,12 @@ bool slices_fit(int h, int w, int n_views) {
 extern "C" size_t mvx_unproject_backward_workspace_bytes(int64_t n_frames, int n_views, int n_channels, int h, int w,
                                                          int vx, int vy, int vz, int aggregation) {
     if (n_frames <= 0 || n_views <= 0 || n_channels <= 0 || h <= 0 || w <= 0 || vx <= 0 || vy <= 0 || vz <= 0) return 0;
-    if (aggregation != MVX_AGG_MAX && aggregation != MVX_AGG_SOFTMAX) return 0;
-    if (!mvx::slices_fit(h, w, n_views)) return 0;
-    const size_t pairs = static_cast<size_t>((n_channels + 3) / 4 * 2);
-    const size_t per_pair_voxel = aggregation == MVX_AGG_SOFTMAX ? 16 : 8;
-    return static_cast<size_t>(n_frames) * pairs * vx * vy * vz * per_pair_voxel;
+    if (aggregation == MVX_AGG_SUM || !mvx::slices_fit(h, w, n_views, n_channels, aggregation)) return 0;
+    const size_t cp = static_cast<size_t>((n_channels + 3) / 4 * 4);
+    const size_t n_voxels = static_cast<size_t>(vx) * vy * vz;
+    if (aggregation == MVX_AGG_CONF)  // per run of voxels, the sums of gradient x sample (float64)
+        return static_cast<size_t>(n_frames) * ((n_voxels + mvx::kConfChunk - 1) / mvx::kConfChunk) * n_views * cp * sizeof(double);
+    return static_cast<size_t>(n_frames) * n_views * cp * n_voxels * sizeof(float);
 }
 
 extern "C" int mvx_unproject_backward(const float* features_cl, const float* proj, const float* coords,
@@ -538,7 +548,7 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
     MVX_REQUIRE(grad_features_cl != nullptr && aligned16(grad_features_cl), MVX_ERR_INVALID_ARGUMENT,
                 "%s: grad_features_cl must be a 16-byte aligned device pointer", name);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool in_lds = slices_fit(h, w, V) && n_voxels > 0 && n_frames * V * (Cp / 2) <= 0x7fffffffLL;
+    const bool in_lds = slices_fit(h, w, V, C, aggregation) && n_voxels > 0 && n_frames * V * (Cp / 2) <= 0x7fffffffLL;
     if (!in_lds) {  // the any-shape kernel adds into gradients that start at zero (and an empty grid leaves them zero)
         hipError_t e = hipMemsetAsync(grad_features_cl, 0, static_cast<size_t>(n_frames) * V * map * sizeof(float), st);
         if (e == hipSuccess && grad_vol_conf != nullptr)
@@ -561,19 +571,20 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
     // rounds of frames, so that a one-lane-per-voxel launch stays below 2^31 workgroups
     const int64_t per_round = n_voxels >= (1LL << 38) ? 1 : (1LL << 38) / n_voxels;
     if (in_lds) {
-        const bool with_stats = aggregation == MVX_AGG_MAX || aggregation == MVX_AGG_SOFTMAX;
-        float* stats = nullptr;
-        if (with_stats) {
+        const bool with_factors = aggregation == MVX_AGG_MAX || aggregation == MVX_AGG_SOFTMAX;
+        float* factors = nullptr;
+        if (with_factors) {
             const size_t need = mvx_unproject_backward_workspace_bytes(n_frames, V, C, h, w, vx, vy, vz, aggregation);
             MVX_REQUIRE(workspace != nullptr && workspace_bytes >= need, MVX_ERR_WORKSPACE,
                         "%s: workspace of %zu bytes is too small (%zu needed)", name, workspace_bytes, need);
             MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", name);
-            stats = static_cast<float*>(workspace);
+            factors = static_cast<float*>(workspace);
             const size_t per_frame = need / static_cast<size_t>(n_frames) / sizeof(float);
-            for (int64_t f0 = 0; f0 < n_frames; f0 += per_round) {
-                const int64_t nf = (n_frames - f0 < per_round) ? n_frames - f0 : per_round;
-                const int64_t n_total = nf * n_voxels;
-                const int64_t blocks = (n_total + kBackwardThreads - 1) / kBackwardThreads;
+            const int64_t round = per_round / (Cp / 4) > 0 ? per_round / (Cp / 4) : 1;
+            for (int64_t f0 = 0; f0 < n_frames; f0 += round) {
+                const int64_t nf = (n_frames - f0 < round) ? n_frames - f0 : round;
+                const int64_t n_items = nf * n_voxels * (Cp / 4);
+                const int64_t blocks = (n_items + kBackwardThreads - 1) / kBackwardThreads;
                 MVX_REQUIRE(blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
                 VoxelSource cd{};
                 cd.volume = coords + f0 * n_voxels * 3;
@@ -581,20 +592,34 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
                 cd.vy = vy;
                 cd.vz = vz;
                 if (aggregation == MVX_AGG_MAX)
-                    hipLaunchKernelGGL(unproject_view_stats<MVX_AGG_MAX>, dim3(static_cast<unsigned>(blocks)),
+                    hipLaunchKernelGGL(unproject_view_factors<MVX_AGG_MAX>, dim3(static_cast<unsigned>(blocks)),
                                        dim3(kBackwardThreads), 0, st, features_cl + f0 * V * map, proj + f0 * V * 12, cd,
-                                       n_total, V, Cp, h, w, n_voxels, sx, sy, stats + f0 * per_frame);
+                                       n_items, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
                 else
-                    hipLaunchKernelGGL(unproject_view_stats<MVX_AGG_SOFTMAX>, dim3(static_cast<unsigned>(blocks)),
+                    hipLaunchKernelGGL(unproject_view_factors<MVX_AGG_SOFTMAX>, dim3(static_cast<unsigned>(blocks)),
                                        dim3(kBackwardThreads), 0, st, features_cl + f0 * V * map, proj + f0 * V * 12, cd,
-                                       n_total, V, Cp, h, w, n_voxels, sx, sy, stats + f0 * per_frame);
-                MVX_CHECK_LAUNCH("mvx_unproject_backward (view statistics)");
+                                       n_items, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
+                MVX_CHECK_LAUNCH("mvx_unproject_backward (view factors)");
             }
         }
         VoxelSource cd{};
         cd.volume = coords;
         cd.vy = vy;
         cd.vz = vz;
+        double* conf_partial = nullptr;
+        const int conf_runs = static_cast<int>((n_voxels + kConfChunk - 1) / kConfChunk);
+        if (aggregation == MVX_AGG_CONF && grad_vol_conf != nullptr) {
+            const size_t need = mvx_unproject_backward_workspace_bytes(n_frames, V, C, h, w, vx, vy, vz, aggregation);
+            MVX_REQUIRE(workspace != nullptr && workspace_bytes >= need, MVX_ERR_WORKSPACE,
+                        "%s: workspace of %zu bytes is too small (%zu needed)", name, workspace_bytes, need);
+            MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", name);
+            MVX_REQUIRE(n_frames * conf_runs <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
+            conf_partial = static_cast<double*>(workspace);
+            hipLaunchKernelGGL(unproject_confidence_sums, dim3(static_cast<unsigned>(n_frames * conf_runs)),
+                               dim3(kBackwardThreads), 0, st, features_cl, proj, cd, grad_volumes, conf_runs, V, C, Cp, h, w,
+                               n_voxels, sx, sy, conf_partial);
+            MVX_CHECK_LAUNCH("mvx_unproject_backward (confidence sums)");
+        }
         const size_t lds = static_cast<size_t>(h) * slice_row(w) * sizeof(double);
         const dim3 grid(static_cast<unsigned>(n_frames * V * (Cp / 2)));
 #define MVX_LAUNCH_BACKWARD_MAPS(AGG)                                                                                  \
@@ -602,8 +627,9 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(unproject_backward_maps<AGG>),               \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));        \
         MVX_REQUIRE(ea == hipSuccess, MVX_ERR_HIP, "%s: %zu bytes of LDS refused: %s", name, lds, hipGetErrorString(ea)); \
-        hipLaunchKernelGGL(unproject_backward_maps<AGG>, grid, dim3(kMapsThreads), lds, st, features_cl, proj, cd, vol_conf, \
-                           grad_volumes, stats, V, C, Cp, h, w, n_voxels, sx, sy, grad_features_cl, grad_vol_conf);    \
+        hipLaunchKernelGGL(unproject_backward_maps<AGG>, grid, dim3(kMapsThreads), lds, st, proj, cd, vol_conf, grad_volumes, \
+                           factors, conf_partial, conf_runs, V, C, Cp, h, w, n_voxels, sx, sy, grad_features_cl,       \
+                           grad_vol_conf);                                                                             \
     } while (0)
         switch (aggregation) {
             case MVX_AGG_SUM: MVX_LAUNCH_BACKWARD_MAPS(MVX_AGG_SUM); break;
