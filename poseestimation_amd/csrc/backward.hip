@@ -195,42 +195,52 @@ __host__ __device__ inline int slice_row(int W) { return 2 * W + 1; }  // double
 // For max and softmax, before the slice kernel: the derivative of the aggregate with respect to every view's
 // sample, factors[frame][view][channel pair][voxel] (float2) -- 1 for the first view that holds the maximum and 0 for
 // the others (max), s_v (1 + x_v - out) with s the softmax over the views' samples x (softmax: out = sum_v s_v x_v).
-// One lane per (voxel, channel quad), consecutive lanes the quads of one voxel, so that 8 lanes read one whole
-// 128-byte pixel (for 32 channels) and the texture path serves a tap of 8 voxels per instruction rather than of one.
-// The views are sampled twice (the second time out of L1): the number of views is not known at compile time.
+// A workgroup takes 256 / (Cp / 4) consecutive voxels.  First its threads project them, one (view, voxel) each, and
+// leave the taps in LDS; then one lane per (voxel, channel quad), consecutive lanes the quads of one voxel, so that
+// 8 lanes read one whole 128-byte pixel (for 32 channels) and the texture path serves a tap of 8 voxels per
+// instruction rather than of one.  The views are sampled twice (the second time out of L1): their number is not
+// known at compile time.  Dynamic LDS: V * (256 / (Cp / 4)) taps.
 template <int AGG>
 __global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
-    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, int64_t n_items, int V, int Cp,
+    const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, int64_t n_total, int V, int Cp,
     int H, int W, int64_t n_vox, double sx, double sy, float* __restrict__ factors) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBackwardThreads + threadIdx.x;
-    if (idx >= n_items) return;
+    extern __shared__ Tap taps[];  // [V][voxels of the workgroup]
     const int Cq = Cp / 4, pairs = Cp / 2;
-    const int q = static_cast<int>(idx % Cq);
-    const int64_t bn = idx / Cq;
-    const int64_t b = bn / n_vox, n = bn - b * n_vox;
-    double X, Y, Z;
-    voxel_position(coord, b, n_vox, n, X, Y, Z);
+    const int vpw = kBackwardThreads / Cq;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * vpw;
+    for (int i = threadIdx.x; i < vpw * V; i += kBackwardThreads) {
+        const int u = i / vpw, vl = i - u * vpw;
+        const int64_t at = first + vl;
+        if (at >= n_total) continue;
+        const int64_t b = at / n_vox, n = at - b * n_vox;
+        double X, Y, Z, Pd[12];
+        voxel_position(coord, b, n_vox, n, X, Y, Z);
+        load_camera(proj, b * V + u, sx, sy, Pd);
+        taps[u * vpw + vl] = project_tap(Pd, X, Y, Z, H, W, 1.0f);
+    }
+    __syncthreads();
+    const int vl = threadIdx.x / Cq, q = threadIdx.x - vl * Cq;
+    const int64_t at = first + vl;
+    if (vl >= vpw || at >= n_total) return;
+    const int64_t b = at / n_vox, n = at - b * n_vox;
     const size_t map = static_cast<size_t>(H) * W * Cp;
     float top[4], den[4], num[4];
-    int first[4];
+    int best[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         top[k] = -INFINITY;
         den[k] = 0.0f;
         num[k] = 0.0f;
-        first[k] = 0;
+        best[k] = 0;
     }
     for (int u = 0; u < V; ++u) {
-        double Pd[12];
-        load_camera(proj, b * V + u, sx, sy, Pd);
-        const Tap t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
         float val[4];
-        sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q, val);
+        sample_quad(feat_cl + (b * V + u) * map, taps[u * vpw + vl], W, Cp, q, val);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (AGG == MVX_AGG_MAX) {
                 const bool up = (u == 0) || (val[k] > top[k]);  // strictly greater: the first maximal view stays
-                first[k] = up ? u : first[k];
+                best[k] = up ? u : best[k];
                 top[k] = up ? val[k] : top[k];
             } else {  // running maximum; what is summed so far is rescaled when it moves
                 const float dd = val[k] - top[k];
@@ -253,13 +263,10 @@ __global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
         float f[4];
         if (AGG == MVX_AGG_MAX) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) f[k] = first[k] == u ? 1.0f : 0.0f;
+            for (int k = 0; k < 4; ++k) f[k] = best[k] == u ? 1.0f : 0.0f;
         } else {
-            double Pd[12];
-            load_camera(proj, b * V + u, sx, sy, Pd);
-            const Tap t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
             float val[4];
-            sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q, val);
+            sample_quad(feat_cl + (b * V + u) * map, taps[u * vpw + vl], W, Cp, q, val);
 #pragma unroll
             for (int k = 0; k < 4; ++k) f[k] = exp_neg(val[k] - top[k]) * rden[k] * (1.0f + val[k] - out[k]);
         }
@@ -580,11 +587,13 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
             MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", name);
             factors = static_cast<float*>(workspace);
             const size_t per_frame = need / static_cast<size_t>(n_frames) / sizeof(float);
-            const int64_t round = per_round / (Cp / 4) > 0 ? per_round / (Cp / 4) : 1;
-            for (int64_t f0 = 0; f0 < n_frames; f0 += round) {
-                const int64_t nf = (n_frames - f0 < round) ? n_frames - f0 : round;
-                const int64_t n_items = nf * n_voxels * (Cp / 4);
-                const int64_t blocks = (n_items + kBackwardThreads - 1) / kBackwardThreads;
+            MVX_REQUIRE(Cp / 4 <= kBackwardThreads, MVX_ERR_UNSUPPORTED, "%s: more than %d channels", name, 4 * kBackwardThreads);
+            const int vpw = kBackwardThreads / (Cp / 4);
+            const size_t taps_lds = static_cast<size_t>(V) * vpw * sizeof(Tap);
+            for (int64_t f0 = 0; f0 < n_frames; f0 += per_round) {
+                const int64_t nf = (n_frames - f0 < per_round) ? n_frames - f0 : per_round;
+                const int64_t n_total = nf * n_voxels;
+                const int64_t blocks = (n_total + vpw - 1) / vpw;
                 MVX_REQUIRE(blocks <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
                 VoxelSource cd{};
                 cd.volume = coords + f0 * n_voxels * 3;
@@ -593,12 +602,12 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
                 cd.vz = vz;
                 if (aggregation == MVX_AGG_MAX)
                     hipLaunchKernelGGL(unproject_view_factors<MVX_AGG_MAX>, dim3(static_cast<unsigned>(blocks)),
-                                       dim3(kBackwardThreads), 0, st, features_cl + f0 * V * map, proj + f0 * V * 12, cd,
-                                       n_items, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
+                                       dim3(kBackwardThreads), taps_lds, st, features_cl + f0 * V * map, proj + f0 * V * 12,
+                                       cd, n_total, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
                 else
                     hipLaunchKernelGGL(unproject_view_factors<MVX_AGG_SOFTMAX>, dim3(static_cast<unsigned>(blocks)),
-                                       dim3(kBackwardThreads), 0, st, features_cl + f0 * V * map, proj + f0 * V * 12, cd,
-                                       n_items, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
+                                       dim3(kBackwardThreads), taps_lds, st, features_cl + f0 * V * map, proj + f0 * V * 12,
+                                       cd, n_total, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
                 MVX_CHECK_LAUNCH("mvx_unproject_backward (view factors)");
             }
         }
