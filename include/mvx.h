@@ -236,9 +236,10 @@ int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, 
  *                   per (view, channel, voxel) -- the size of the per-view volumes of the reference, 134 MB per frame
  *                   for 4 views x 32 channels x 64^3; for MVX_AGG_CONF the partial sums behind grad_vol_conf (about
  *                   1 KB per frame, view and 2048 voxels); 0 bytes for MVX_AGG_SUM (NULL allowed)
- * Maps of up to about 9 600 pixels (96 x 96 fits) and up to 16 views accumulate slices of the gradient in LDS, in
- * float64, and are written once (no atomics in global memory; two runs agree except for float64 rounding before the
- * final conversion); other shapes use float32 atomic additions in global memory in no fixed order.
+ * Slices of the gradient (two channels of one view's map; larger maps in bands of rows) are accumulated in LDS in
+ * float64 and written once: no atomics in global memory, and two runs agree except for float64 rounding before the
+ * final conversion.  Shapes that path does not take (rows of more than about 9 700 pixels; with grad_vol_conf more than
+ * 64 channels or 16 views) use float32 atomic additions in global memory in no fixed order.
  */
 size_t mvx_unproject_backward_workspace_bytes(int64_t n_frames, int n_views, int n_channels, int h, int w, int vx, int vy,
                                               int vz, int aggregation);

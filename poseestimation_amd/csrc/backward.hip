@@ -9,8 +9,8 @@
 //   unproject_backward_maps  one 1024-thread workgroup per (frame, view, 2 channels) keeps that slice of the gradient
 //                            -- the whole h x w map in float64, 145 KB for 96 x 96 -- in LDS, walks all voxels of the
 //                            frame adding into it with LDS atomics, and writes the slice once, rounded to float32, with
-//                            plain stores.  No global atomics, no clearing pass; for maps of up to about 9 600 pixels
-//                            and up to 16 views.  float64 because that is the fast LDS atomic on gfx950: ds_add_f64
+//                            plain stores.  No global atomics, no clearing pass.  Larger maps are cut into bands of
+//                            rows, one workgroup each.  float64 because that is the fast LDS atomic on gfx950: ds_add_f64
 //                            retires 4 to 7 lanes per clock per CU, ds_add_f32 one lane per 3 clocks whatever the
 //                            addresses (tools/lds_atomic_rate.hip) -- and the sums come out exact to float32 rounding.
 //                            Rows of the slice are padded by one element: the voxels of a wave lie along one grid
@@ -26,10 +26,11 @@
 //   unproject_confidence_sums  confidence aggregation with the confidences' gradient wanted, before the slice kernel:
 //                            sum over voxels of gradient x sample per (view, channel), in runs of 2048 voxels whose
 //                            totals the slice kernel adds up in order.
-//   unproject_backward       any shape: one lane per voxel, float32 atomic adds at agent scope into a gradient the
-//                            entry point has zeroed (for 8 frames of the model's shape 52 ms: every addition is a
-//                            round trip to the memory side, and their order is not fixed: two runs differ in the last
-//                            bits).
+//   unproject_backward       whatever the kernels above do not take (rows of more than 9 700 pixels, more than 64
+//                            channels or 16 views with the confidences' gradient): one lane per voxel, float32 atomic
+//                            adds at agent scope into a gradient the entry point has zeroed (for 8 frames of the
+//                            model's shape 52 ms: every addition is a round trip to the memory side, and their order
+//                            is not fixed: two runs differ in the last bits).
 //
 // 3-D soft-argmax.  With p the forward's output volume, X_i the coordinates of voxel i, gc the gradient of the
 // volume's coordinates and gp_i the gradient of p_i, G_i = gp_i + gc . X_i and
@@ -325,25 +326,31 @@ __global__ __launch_bounds__(kBackwardThreads) void unproject_confidence_sums(
     for (int i = tid; i < V * Cp; i += kBackwardThreads) out[i] = acc[i];
 }
 
-// One workgroup per (frame, view, channel pair): the slice [h][w][2] of the gradient lives in LDS as float64, rows
-// padded to slice_row(W).  Dynamic LDS: H * slice_row(W) doubles.  Channels c0 = 2 * pair and c0 + 1.
+// One workgroup per (frame, view, channel pair, band of rows): the slice [rows][w][2] of the gradient lives in LDS as
+// float64, rows padded to slice_row(W).  Dynamic LDS: band_rows * slice_row(W) doubles.  Channels c0 = 2 * pair and
+// c0 + 1.  A map of up to about 9 600 pixels is one band; a larger one is cut into bands of band_rows rows, each walked
+// by a workgroup of its own that keeps the taps falling into its rows.
 template <int AGG>
 __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
     const float* __restrict__ proj, VoxelSource coord, const float* __restrict__ vconf, const float* __restrict__ g_vol, const float* __restrict__ factors,
-    const double* __restrict__ conf_partial, int conf_runs, int V, int C, int Cp, int H, int W, int64_t n_vox, double sx,
-    double sy, float* __restrict__ g_feat_cl, float* __restrict__ g_conf) {
+    const double* __restrict__ conf_partial, int conf_runs, int V, int C, int Cp, int H, int W, int bands, int band_rows,
+    int64_t n_vox, double sx, double sy, float* __restrict__ g_feat_cl, float* __restrict__ g_conf) {
     extern __shared__ double slice[];
     __shared__ double cam[12];
     const int tid = threadIdx.x;
     const int pairs = Cp / 2;
     unsigned id = blockIdx.x;
+    const int band = static_cast<int>(id % bands);
+    id /= bands;
     const int pair = static_cast<int>(id % pairs);
     id /= pairs;
     const int v = static_cast<int>(id % V);
     const int64_t b = id / V;
     const int c0 = 2 * pair;  // c0 + 1 may be padding
     const int RS = slice_row(W);
-    for (int i = tid; i < H * RS; i += kMapsThreads) slice[i] = 0.0;
+    const int y_first = band * band_rows;
+    const int rows = (H - y_first < band_rows) ? H - y_first : band_rows;
+    for (int i = tid; i < rows * RS; i += kMapsThreads) slice[i] = 0.0;
     if (tid < 12) cam[tid] = camera_entry(proj + (b * V + v) * 12, tid, sx, sy);
     __syncthreads();
     const size_t map = static_cast<size_t>(H) * W * Cp;
@@ -370,24 +377,27 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
             d[0] = AGG == MVX_AGG_CONF ? g[0] * conf[0] : g[0];
             d[1] = AGG == MVX_AGG_CONF ? g[1] * conf[1] : g[1];
         }
-        double* p = slice + t.yb * RS + 2 * t.xb;
+        const int r0 = t.yb - y_first;  // the taps' upper row, relative to this band
+        double* p = slice + r0 * RS + 2 * t.xb;
         const float w4[4] = {t.w00, t.w01, t.w10, t.w11};
         const int off[4] = {0, 2, RS, RS + 2};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (w4[i] == 0.0f) continue;  // outside the map, or behind the camera: the reference passes no gradient
+            // nothing for a tap outside the map or a voxel behind the camera (the reference passes no gradient there),
+            // nor for a row that belongs to another band
+            if (w4[i] == 0.0f || static_cast<unsigned>(r0 + (i >> 1)) >= static_cast<unsigned>(rows)) continue;
 #pragma unroll
             for (int k = 0; k < 2; ++k) atomicAdd(p + off[i] + k, static_cast<double>(d[k]) * static_cast<double>(w4[i]));
         }
     }
     __syncthreads();
-    float* out = g_feat_cl + (b * V + v) * map + c0;
-    for (int i = tid; i < H * W; i += kMapsThreads) {
+    float* out = g_feat_cl + (b * V + v) * map + static_cast<size_t>(y_first) * W * Cp + c0;
+    for (int i = tid; i < rows * W; i += kMapsThreads) {
         const int y = i / W, x = i - y * W;
         const double* e = slice + y * RS + 2 * x;
         *reinterpret_cast<float2*>(out + static_cast<size_t>(i) * Cp) = make_float2(static_cast<float>(e[0]), static_cast<float>(e[1]));
     }
-    if (wants_conf && tid < 2 && c0 + tid < C) {  // the runs' sums of gradient x sample, added in run order
+    if (wants_conf && band == 0 && tid < 2 && c0 + tid < C) {  // the runs' sums of gradient x sample, added in run order
         double total = 0.0;
         for (int r = 0; r < conf_runs; ++r) total += conf_partial[((static_cast<size_t>(b) * conf_runs + r) * V + v) * Cp + c0 + tid];
         g_conf[(b * V + v) * C + c0 + tid] = static_cast<float>(total);
@@ -515,10 +525,23 @@ inline int volume_segments(int64_t count, int64_t N) {
     return s < 1 ? 1 : static_cast<int>(s);
 }
 
+// Rows of a map that one slice holds (all of them for maps of up to about 9 600 pixels); 0: not even two rows fit.
+int slice_band_rows(int h, int w) {
+    const size_t row_bytes = static_cast<size_t>(slice_row(w)) * sizeof(double);
+    const size_t fit = kMapsMaxSliceBytes / row_bytes;
+    if (fit < 2) return 0;
+    return fit >= static_cast<size_t>(h) ? h : static_cast<int>(fit);
+}
+
 bool slices_fit(int h, int w, int n_views, int n_channels, int aggregation) {
-    return static_cast<size_t>(h) * slice_row(w) * sizeof(double) <= kMapsMaxSliceBytes && n_views <= kMapsMaxViews &&
-           (aggregation != MVX_AGG_CONF || (n_channels + 3) / 4 * 4 <= kConfMaxChannels) &&
-           !(kernel_selection() & MVX_SELECT_NO_BACKWARD_IN_LDS);
+    const int cp = (n_channels + 3) / 4 * 4;
+    if (slice_band_rows(h, w) == 0 || cp / 4 > kBackwardThreads) return false;
+    // the pre-passes keep per-view data of a workgroup in LDS
+    if (aggregation == MVX_AGG_CONF && (cp > kConfMaxChannels || n_views > kMapsMaxViews)) return false;
+    if ((aggregation == MVX_AGG_MAX || aggregation == MVX_AGG_SOFTMAX) &&
+        static_cast<size_t>(n_views) * (kBackwardThreads / (cp / 4)) * sizeof(Tap) > 48 * 1024)
+        return false;
+    return !(kernel_selection() & MVX_SELECT_NO_BACKWARD_IN_LDS);
 }
 
 }  // namespace
@@ -555,7 +578,10 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
     MVX_REQUIRE(grad_features_cl != nullptr && aligned16(grad_features_cl), MVX_ERR_INVALID_ARGUMENT,
                 "%s: grad_features_cl must be a 16-byte aligned device pointer", name);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool in_lds = slices_fit(h, w, V, C, aggregation) && n_voxels > 0 && n_frames * V * (Cp / 2) <= 0x7fffffffLL;
+    const int band_rows = slice_band_rows(h, w);
+    const int bands = band_rows > 0 ? (h + band_rows - 1) / band_rows : 1;
+    const bool in_lds = slices_fit(h, w, V, C, aggregation) && n_voxels > 0 &&
+                        n_frames * V * (Cp / 2) * bands <= 0x7fffffffLL;
     if (!in_lds) {  // the any-shape kernel adds into gradients that start at zero (and an empty grid leaves them zero)
         hipError_t e = hipMemsetAsync(grad_features_cl, 0, static_cast<size_t>(n_frames) * V * map * sizeof(float), st);
         if (e == hipSuccess && grad_vol_conf != nullptr)
@@ -587,7 +613,6 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
             MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", name);
             factors = static_cast<float*>(workspace);
             const size_t per_frame = need / static_cast<size_t>(n_frames) / sizeof(float);
-            MVX_REQUIRE(Cp / 4 <= kBackwardThreads, MVX_ERR_UNSUPPORTED, "%s: more than %d channels", name, 4 * kBackwardThreads);
             const int vpw = kBackwardThreads / (Cp / 4);
             const size_t taps_lds = static_cast<size_t>(V) * vpw * sizeof(Tap);
             for (int64_t f0 = 0; f0 < n_frames; f0 += per_round) {
@@ -629,16 +654,16 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
                                n_voxels, sx, sy, conf_partial);
             MVX_CHECK_LAUNCH("mvx_unproject_backward (confidence sums)");
         }
-        const size_t lds = static_cast<size_t>(h) * slice_row(w) * sizeof(double);
-        const dim3 grid(static_cast<unsigned>(n_frames * V * (Cp / 2)));
+        const size_t lds = static_cast<size_t>(band_rows) * slice_row(w) * sizeof(double);
+        const dim3 grid(static_cast<unsigned>(n_frames * V * (Cp / 2) * bands));
 #define MVX_LAUNCH_BACKWARD_MAPS(AGG)                                                                                  \
     do {                                                                                                               \
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(unproject_backward_maps<AGG>),               \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));        \
         MVX_REQUIRE(ea == hipSuccess, MVX_ERR_HIP, "%s: %zu bytes of LDS refused: %s", name, lds, hipGetErrorString(ea)); \
         hipLaunchKernelGGL(unproject_backward_maps<AGG>, grid, dim3(kMapsThreads), lds, st, proj, cd, vol_conf, grad_volumes, \
-                           factors, conf_partial, conf_runs, V, C, Cp, h, w, n_voxels, sx, sy, grad_features_cl,       \
-                           grad_vol_conf);                                                                             \
+                           factors, conf_partial, conf_runs, V, C, Cp, h, w, bands, band_rows, n_voxels, sx, sy,       \
+                           grad_features_cl, grad_vol_conf);                                                           \
     } while (0)
         switch (aggregation) {
             case MVX_AGG_SUM: MVX_LAUNCH_BACKWARD_MAPS(MVX_AGG_SUM); break;

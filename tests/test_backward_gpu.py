@@ -156,15 +156,32 @@ def test_unproject_gradients_model_shapes(views, method, backward_kernel):
     assert np.abs(f64.grad.cpu().numpy() - o_maps).max() <= 1e-5 * scale
 
 
-def test_unproject_gradients_of_maps_too_large_for_lds():
-    """112 x 112 maps (12 544 pixels: no 4-channel slice fits 160 KB of LDS) go through the global-atomics kernel."""
+@pytest.mark.parametrize("method", ["sum", "conf", "max", "softmax"])
+def test_unproject_gradients_of_maps_cut_into_bands(method, backward_kernel):
+    """112 x 112 maps (12 544 pixels) do not fit one LDS slice: the slice kernel walks them in two bands of rows;
+    taps whose two rows fall into different bands are split between the workgroups."""
     case = synth.volumetric_case(4400, 1, 3, n_channels=8, volume_size=16, heatmap_size=112, with_volumes=False)
-    feats, proj, coord = (case[k] for k in ("features", "proj", "coord_volumes"))
+    feats, proj, coord, vconf = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences"))
     up = np.random.default_rng(5).standard_normal((1, 8, 16, 16, 16)).astype(np.float32)
-    f = t(feats, True)
-    (op.unproject_heatmaps(f, t(proj), t(coord), "softmax") * t(up)).sum().backward()
-    want, _ = orc.unproject_heatmaps_backward(feats, proj, coord, up, "softmax")
+    f, c = t(feats, True), t(vconf, True)
+    (op.unproject_heatmaps(f, t(proj), t(coord), method, c) * t(up)).sum().backward()
+    want, want_conf = orc.unproject_heatmaps_backward(feats, proj, coord, up, method, vconf)
     assert np.abs(f.grad.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    if method == "conf":
+        assert np.abs(c.grad.cpu().numpy() - want_conf).max() <= 2e-5 * np.abs(want_conf).max()
+
+
+def test_unproject_gradients_many_views_take_the_any_shape_kernel():
+    """20 views with the confidences' gradient wanted: more per-view sums than the pre-pass keeps in LDS, so the call
+    goes to the global-atomics kernel by itself."""
+    case = synth.volumetric_case(4500, 1, 20, n_channels=4, volume_size=8, heatmap_size=24, with_volumes=False)
+    feats, proj, coord, vconf = (case[k] for k in ("features", "proj", "coord_volumes", "vol_confidences"))
+    up = np.random.default_rng(6).standard_normal((1, 4, 8, 8, 8)).astype(np.float32)
+    f, c = t(feats, True), t(vconf, True)
+    (op.unproject_heatmaps(f, t(proj), t(coord), "conf", c) * t(up)).sum().backward()
+    want, want_conf = orc.unproject_heatmaps_backward(feats, proj, coord, up, "conf", vconf)
+    assert np.abs(f.grad.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.abs(c.grad.cpu().numpy() - want_conf).max() <= 2e-5 * np.abs(want_conf).max()
 
 
 def test_unproject_gradient_is_linear_and_deterministic_enough():
