@@ -408,23 +408,64 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
 constexpr int kVolumeThreads = 512;
 constexpr int kMaxSegments = 16;
 
-// Position of voxel i: its coordinates, or its indices.
-__device__ __forceinline__ void voxel_xyz(const float* __restrict__ xyz, int64_t i, int vy, int vz, double (&x)[3]) {
-    if (xyz != nullptr) {
-        x[0] = xyz[3 * i];
-        x[1] = xyz[3 * i + 1];
-        x[2] = xyz[3 * i + 2];
+// Four consecutive voxels starting at i (a multiple of 4): probabilities, their gradients and positions.
+struct Voxels4 {
+    float p[4], gp[4];
+    double x[4][3];
+};
+template <bool VEC>
+__device__ __forceinline__ Voxels4 load_voxels(const float* __restrict__ p, const float* __restrict__ gp,
+                                               const float* __restrict__ xyz, int64_t i, int count, int vy, int vz) {
+    Voxels4 r;
+    if (VEC) {  // 16-byte loads: N is a multiple of 4 and the arrays are 16-byte aligned
+        const float4 pv = *reinterpret_cast<const float4*>(p + i);
+        r.p[0] = pv.x, r.p[1] = pv.y, r.p[2] = pv.z, r.p[3] = pv.w;
+        if (gp != nullptr) {
+            const float4 gv = *reinterpret_cast<const float4*>(gp + i);
+            r.gp[0] = gv.x, r.gp[1] = gv.y, r.gp[2] = gv.z, r.gp[3] = gv.w;
+        }
+        if (xyz != nullptr) {
+            const float4 a = *reinterpret_cast<const float4*>(xyz + 3 * i);
+            const float4 b = *reinterpret_cast<const float4*>(xyz + 3 * i + 4);
+            const float4 c = *reinterpret_cast<const float4*>(xyz + 3 * i + 8);
+            const float f[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) r.x[j][d] = f[3 * j + d];
+            }
+        }
     } else {
-        const int64_t row = i / vz;
-        x[2] = static_cast<double>(i - row * vz);
-        x[0] = static_cast<double>(row / vy);
-        x[1] = static_cast<double>(row - (row / vy) * vy);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r.p[j] = j < count ? p[i + j] : 0.0f;
+            if (gp != nullptr) r.gp[j] = j < count ? gp[i + j] : 0.0f;
+            if (xyz != nullptr) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) r.x[j][d] = j < count ? xyz[3 * (i + j) + d] : 0.0f;
+            }
+        }
     }
+    if (gp == nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.gp[j] = 0.0f;
+    }
+    if (xyz == nullptr) {  // the voxel indices themselves
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row = (i + j) / vz;
+            r.x[j][2] = static_cast<double>(i + j - row * vz);
+            r.x[j][0] = static_cast<double>(row / vy);
+            r.x[j][1] = static_cast<double>(row - (row / vy) * vy);
+        }
+    }
+    return r;
 }
 
 // mode 0: softmax; 1: ReLU, coordinates not divided by the mass; 2: ReLU, coordinates divided by the mass.
 // Workgroup (volume, segment) leaves in partial[(volume * segments + segment) * 4 ..]: mode 0 sum p G; mode 2 the
-// mass and the first moments of p.
+// mass and the first moments of p.  A lane takes four consecutive voxels per round (seg_len is a multiple of 4).
+template <bool VEC>
 __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_sums(
     const float* __restrict__ probs, const float* __restrict__ coords, int n_volumes, int vy, int vz, int64_t N,
     int segments, int64_t seg_len, int mode, const float* __restrict__ g_coords, const float* __restrict__ g_probs,
@@ -443,18 +484,21 @@ __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_sums(
     }
     const int64_t i0 = seg * seg_len, i1 = (i0 + seg_len < N) ? i0 + seg_len : N;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += kVolumeThreads) {
-        double x[3];
-        voxel_xyz(xyz, i, vy, vz, x);
-        const double pi = p[i];
-        if (mode == 0) {
-            const double G = (gp != nullptr ? static_cast<double>(gp[i]) : 0.0) + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
-            s[0] += pi * G;
-        } else {
-            s[0] += pi;
-            s[1] += pi * x[0];
-            s[2] += pi * x[1];
-            s[3] += pi * x[2];
+    for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kVolumeThreads) {
+        const int count = (i1 - i < 4) ? static_cast<int>(i1 - i) : 4;
+        const Voxels4 v = load_voxels<VEC>(p, gp, xyz, i, count, vy, vz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double pi = v.p[j];  // zero beyond the segment's end
+            if (mode == 0) {
+                const double G = static_cast<double>(v.gp[j]) + gc[0] * v.x[j][0] + gc[1] * v.x[j][1] + gc[2] * v.x[j][2];
+                s[0] += pi * G;
+            } else {
+                s[0] += pi;
+                s[1] += pi * v.x[j][0];
+                s[2] += pi * v.x[j][1];
+                s[3] += pi * v.x[j][2];
+            }
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -471,6 +515,7 @@ __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_sums(
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_write(
     const float* __restrict__ probs, const float* __restrict__ coords, int n_volumes, int vy, int vz, int64_t N,
     int segments, int64_t seg_len, float multiplier, int mode, const float* __restrict__ g_coords,
@@ -498,20 +543,31 @@ __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_write(
     const double dot = s[0], mass = s[0];
     const double c[3] = {s[1] / mass, s[2] / mass, s[3] / mass};
     const int64_t i0 = seg * seg_len, i1 = (i0 + seg_len < N) ? i0 + seg_len : N;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += kVolumeThreads) {
-        double x[3];
-        voxel_xyz(xyz, i, vy, vz, x);
-        const double gpi = gp != nullptr ? static_cast<double>(gp[i]) : 0.0;
-        const float pi = p[i];
-        if (mode == 0) {
-            const double G = gpi + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
-            gx[i] = static_cast<float>(m * static_cast<double>(pi) * (G - dot));
-        } else if (mode == 1) {
-            const double G = gpi + gc[0] * x[0] + gc[1] * x[1] + gc[2] * x[2];
-            gx[i] = pi > 0.0f ? static_cast<float>(m * G) : 0.0f;
+    for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kVolumeThreads) {
+        const int count = (i1 - i < 4) ? static_cast<int>(i1 - i) : 4;
+        const Voxels4 v = load_voxels<VEC>(p, gp, xyz, i, count, vy, vz);
+        float out[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double gpi = v.gp[j];
+            if (mode == 0) {
+                const double G = gpi + gc[0] * v.x[j][0] + gc[1] * v.x[j][1] + gc[2] * v.x[j][2];
+                out[j] = static_cast<float>(m * static_cast<double>(v.p[j]) * (G - dot));
+            } else if (mode == 1) {
+                const double G = gpi + gc[0] * v.x[j][0] + gc[1] * v.x[j][1] + gc[2] * v.x[j][2];
+                out[j] = v.p[j] > 0.0f ? static_cast<float>(m * G) : 0.0f;
+            } else {
+                const double G = gpi + (gc[0] * (v.x[j][0] - c[0]) + gc[1] * (v.x[j][1] - c[1]) + gc[2] * (v.x[j][2] - c[2])) / mass;
+                out[j] = v.p[j] > 0.0f ? static_cast<float>(m * G) : 0.0f;
+            }
+        }
+        if (VEC) {
+            *reinterpret_cast<float4*>(gx + i) = make_float4(out[0], out[1], out[2], out[3]);
         } else {
-            const double G = gpi + (gc[0] * (x[0] - c[0]) + gc[1] * (x[1] - c[1]) + gc[2] * (x[2] - c[2])) / mass;
-            gx[i] = pi > 0.0f ? static_cast<float>(m * G) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < count) gx[i + j] = out[j];
+            }
         }
     }
 }
@@ -726,23 +782,34 @@ extern "C" int mvx_soft_argmax_3d_backward(const float* volumes_out, const float
     MVX_REQUIRE(count * segments <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: too many volumes", name);
     // the reference divides by the mass only in index space (mvn/utils/op.py:73-76)
     const int mode = softmax ? 0 : (coords != nullptr ? 1 : 2);
-    const int64_t seg_len = (N + segments - 1) / segments;
+    const int64_t seg_len = ((N + segments - 1) / segments + 3) / 4 * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(static_cast<unsigned>(count * segments));
     double* partial = static_cast<double*>(workspace);
+    const bool vec = N % 4 == 0 && aligned16(volumes_out) && aligned16(grad_volumes) &&
+                     (coords == nullptr || aligned16(coords)) && (grad_volumes_out == nullptr || aligned16(grad_volumes_out));
     if (mode != 1) {
         MVX_REQUIRE(workspace != nullptr &&
                         workspace_bytes >= mvx_soft_argmax_3d_backward_workspace_bytes(n_frames, n_volumes, sx, sy, sz),
                     MVX_ERR_WORKSPACE, "%s: workspace of %zu bytes is too small", name, workspace_bytes);
         MVX_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, MVX_ERR_INVALID_ARGUMENT,
                     "%s: workspace must be 8-byte aligned", name);
-        hipLaunchKernelGGL(soft_argmax_3d_backward_sums, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords, n_volumes,
-                           sy, sz, N, segments, seg_len, mode, grad_coordinates, grad_volumes_out, partial);
+        if (vec)
+            hipLaunchKernelGGL(soft_argmax_3d_backward_sums<true>, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords,
+                               n_volumes, sy, sz, N, segments, seg_len, mode, grad_coordinates, grad_volumes_out, partial);
+        else
+            hipLaunchKernelGGL(soft_argmax_3d_backward_sums<false>, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords,
+                               n_volumes, sy, sz, N, segments, seg_len, mode, grad_coordinates, grad_volumes_out, partial);
         MVX_CHECK_LAUNCH("mvx_soft_argmax_3d_backward (sums)");
     }
-    hipLaunchKernelGGL(soft_argmax_3d_backward_write, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords, n_volumes, sy,
-                       sz, N, segments, seg_len, multiplier, mode, grad_coordinates, grad_volumes_out, partial,
-                       grad_volumes);
+    if (vec)
+        hipLaunchKernelGGL(soft_argmax_3d_backward_write<true>, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords,
+                           n_volumes, sy, sz, N, segments, seg_len, multiplier, mode, grad_coordinates, grad_volumes_out,
+                           partial, grad_volumes);
+    else
+        hipLaunchKernelGGL(soft_argmax_3d_backward_write<false>, grid, dim3(kVolumeThreads), 0, st, volumes_out, coords,
+                           n_volumes, sy, sz, N, segments, seg_len, multiplier, mode, grad_coordinates, grad_volumes_out,
+                           partial, grad_volumes);
     MVX_CHECK_LAUNCH(name);
     return MVX_OK;
 }
