@@ -193,15 +193,27 @@ constexpr size_t kMapsMaxSliceBytes = 152 * 1024;
 
 __host__ __device__ inline int slice_row(int W) { return 2 * W + 1; }  // doubles per padded row of a slice
 
+// f(u) for every view: unrolled for a number of views known at compile time (NV > 0), a plain loop otherwise.
+template <int NV, typename F>
+__device__ __forceinline__ void for_views(int V, F&& f) {
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) f(u);
+    } else {
+        for (int u = 0; u < V; ++u) f(u);
+    }
+}
+
 // For max and softmax, before the slice kernel: the derivative of the aggregate with respect to every view's
 // sample, factors[frame][view][channel pair][voxel] (float2) -- 1 for the first view that holds the maximum and 0 for
 // the others (max), s_v (1 + x_v - out) with s the softmax over the views' samples x (softmax: out = sum_v s_v x_v).
 // A workgroup takes 256 / (Cp / 4) consecutive voxels.  First its threads project them, one (view, voxel) each, and
 // leave the taps in LDS; then one lane per (voxel, channel quad), consecutive lanes the quads of one voxel, so that
 // 8 lanes read one whole 128-byte pixel (for 32 channels) and the texture path serves a tap of 8 voxels per
-// instruction rather than of one.  The views are sampled twice (the second time out of L1): their number is not
-// known at compile time.  Dynamic LDS: V * (256 / (Cp / 4)) taps.
-template <int AGG>
+// instruction rather than of one.  NV = 2, 3 or 4 views (what the reference's collate function draws) keep the samples
+// in registers between the two passes; NV = 0 is any number of views, sampled a second time (out of L1).
+// Dynamic LDS: V * (256 / (Cp / 4)) taps.
+template <int AGG, int NV>
 __global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
     const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, int64_t n_total, int V, int Cp,
     int H, int W, int64_t n_vox, double sx, double sy, float* __restrict__ factors) {
@@ -234,11 +246,14 @@ __global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
         num[k] = 0.0f;
         best[k] = 0;
     }
-    for (int u = 0; u < V; ++u) {
+    constexpr bool kKeep = NV > 0 && AGG == MVX_AGG_SOFTMAX;
+    float kept[kKeep ? NV : 1][4];
+    for_views<NV>(V, [&](int u) {
         float val[4];
         sample_quad(feat_cl + (b * V + u) * map, taps[u * vpw + vl], W, Cp, q, val);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            if (kKeep) kept[kKeep ? u : 0][k] = val[k];
             if (AGG == MVX_AGG_MAX) {
                 const bool up = (u == 0) || (val[k] > top[k]);  // strictly greater: the first maximal view stays
                 best[k] = up ? u : best[k];
@@ -253,28 +268,33 @@ __global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
                 top[k] = up ? val[k] : top[k];
             }
         }
-    }
+    });
     float rden[4], out[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         rden[k] = 1.0f / den[k];
         out[k] = num[k] * rden[k];
     }
-    for (int u = 0; u < V; ++u) {
+    for_views<NV>(V, [&](int u) {
         float f[4];
         if (AGG == MVX_AGG_MAX) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) f[k] = best[k] == u ? 1.0f : 0.0f;
         } else {
             float val[4];
-            sample_quad(feat_cl + (b * V + u) * map, taps[u * vpw + vl], W, Cp, q, val);
+            if (kKeep) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) val[k] = kept[kKeep ? u : 0][k];
+            } else {
+                sample_quad(feat_cl + (b * V + u) * map, taps[u * vpw + vl], W, Cp, q, val);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) f[k] = exp_neg(val[k] - top[k]) * rden[k] * (1.0f + val[k] - out[k]);
         }
         float2* row = reinterpret_cast<float2*>(factors) + ((static_cast<size_t>(b) * V + u) * pairs + 2 * q) * n_vox + n;
         row[0] = make_float2(f[0], f[1]);
         row[n_vox] = make_float2(f[2], f[3]);
-    }
+    });
 }
 
 // Confidence aggregation, before the slice kernel, when the gradient of the confidences is wanted:
@@ -681,14 +701,22 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
                 cd.first_frame = f0;
                 cd.vy = vy;
                 cd.vz = vz;
-                if (aggregation == MVX_AGG_MAX)
-                    hipLaunchKernelGGL(unproject_view_factors<MVX_AGG_MAX>, dim3(static_cast<unsigned>(blocks)),
-                                       dim3(kBackwardThreads), taps_lds, st, features_cl + f0 * V * map, proj + f0 * V * 12,
-                                       cd, n_total, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
-                else
-                    hipLaunchKernelGGL(unproject_view_factors<MVX_AGG_SOFTMAX>, dim3(static_cast<unsigned>(blocks)),
-                                       dim3(kBackwardThreads), taps_lds, st, features_cl + f0 * V * map, proj + f0 * V * 12,
-                                       cd, n_total, V, Cp, h, w, n_voxels, sx, sy, factors + f0 * per_frame);
+#define MVX_LAUNCH_FACTORS(AGG, NV)                                                                                    \
+    hipLaunchKernelGGL((unproject_view_factors<AGG, NV>), dim3(static_cast<unsigned>(blocks)), dim3(kBackwardThreads),   \
+                       taps_lds, st, features_cl + f0 * V * map, proj + f0 * V * 12, cd, n_total, V, Cp, h, w, n_voxels, \
+                       sx, sy, factors + f0 * per_frame)
+                if (aggregation == MVX_AGG_MAX) {
+                    MVX_LAUNCH_FACTORS(MVX_AGG_MAX, 0);
+                } else if (V == 4) {
+                    MVX_LAUNCH_FACTORS(MVX_AGG_SOFTMAX, 4);
+                } else if (V == 3) {
+                    MVX_LAUNCH_FACTORS(MVX_AGG_SOFTMAX, 3);
+                } else if (V == 2) {
+                    MVX_LAUNCH_FACTORS(MVX_AGG_SOFTMAX, 2);
+                } else {
+                    MVX_LAUNCH_FACTORS(MVX_AGG_SOFTMAX, 0);
+                }
+#undef MVX_LAUNCH_FACTORS
                 MVX_CHECK_LAUNCH("mvx_unproject_backward (view factors)");
             }
         }
