@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MVX_VERSION 100 /* major*10000 + minor*100 + patch */
+#define MVX_VERSION 200 /* major*10000 + minor*100 + patch; 0.2.0 adds the backward entry points */
 
 enum mvx_status {
     MVX_OK = 0,
