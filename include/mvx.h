@@ -252,7 +252,8 @@ int mvx_unproject_backward(const float* features_cl, const float* proj, const fl
  * Backward of mvx_soft_argmax_3d: what torch autograd computes through mvn/utils/op.py:84-96 (coords_volume != NULL)
  * or mvn/utils/op.py:50-81 (coords_volume == NULL: voxel indices, and for softmax == 0 the division by the mass).
  * With p = volumes_out of the forward call and G_i = grad_volumes_out_i + grad_coordinates . X_i:
- *   softmax != 0: grad_volumes_i = multiplier * p_i * (G_i - sum_j p_j G_j);  softmax == 0: multiplier * G_i where
+ *   softmax != 0: grad_volumes_i = multiplier * p_i * (G_i - sum_j p_j G_j / sum_j p_j) (the float32 p add up to 1 only
+ *   to rounding, and G carries the large common offset grad_coordinates . X);  softmax == 0: multiplier * G_i where
  *   p_i > 0 (index space: with X_i - out in place of X_i, divided by sum p).  Sums and G are float64.
  * volumes_out        [n_frames][n_volumes][sx][sy][sz]  what the forward call wrote
  * coords_volume      [n_frames][sx][sy][sz][3] or NULL

@@ -34,7 +34,7 @@
 //
 // 3-D soft-argmax.  With p the forward's output volume, X_i the coordinates of voxel i, gc the gradient of the
 // volume's coordinates and gp_i the gradient of p_i, G_i = gp_i + gc . X_i and
-//   softmax:                 dL/dx_i = m p_i (G_i - sum_j p_j G_j)
+//   softmax:                 dL/dx_i = m p_i (G_i - sum_j p_j G_j / sum_j p_j)
 //   ReLU (with coordinates): dL/dx_i = m G_i where p_i > 0
 //   ReLU (index space, where the reference divides the coordinates by the mass M = sum p; c = the coordinates):
 //                            dL/dx_i = m (gp_i + gc . (X_i - c) / M) where p_i > 0
@@ -483,8 +483,8 @@ __device__ __forceinline__ Voxels4 load_voxels(const float* __restrict__ p, cons
 }
 
 // mode 0: softmax; 1: ReLU, coordinates not divided by the mass; 2: ReLU, coordinates divided by the mass.
-// Workgroup (volume, segment) leaves in partial[(volume * segments + segment) * 4 ..]: mode 0 sum p G; mode 2 the
-// mass and the first moments of p.  A lane takes four consecutive voxels per round (seg_len is a multiple of 4).
+// Workgroup (volume, segment) leaves in partial[(volume * segments + segment) * 4 ..]: mode 0 sum p G and sum p;
+// mode 2 the mass and the first moments of p.  A lane takes four consecutive voxels per round (seg_len is a multiple of 4).
 template <bool VEC>
 __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_sums(
     const float* __restrict__ probs, const float* __restrict__ coords, int n_volumes, int vy, int vz, int64_t N,
@@ -513,6 +513,7 @@ __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_sums(
             if (mode == 0) {
                 const double G = static_cast<double>(v.gp[j]) + gc[0] * v.x[j][0] + gc[1] * v.x[j][1] + gc[2] * v.x[j][2];
                 s[0] += pi * G;
+                s[1] += pi;
             } else {
                 s[0] += pi;
                 s[1] += pi * v.x[j][0];
@@ -560,7 +561,9 @@ __global__ __launch_bounds__(kVolumeThreads) void soft_argmax_3d_backward_write(
         }
     }
     const double m = static_cast<double>(multiplier);
-    const double dot = s[0], mass = s[0];
+    // softmax: the float32 probabilities add up to 1 only to rounding; G carries a large common offset (gc . X with X
+    // in the thousands), so sum p G is divided by sum p, which removes that offset's share of the rounding
+    const double dot = mode == 0 ? s[0] / s[1] : 0.0, mass = s[0];
     const double c[3] = {s[1] / mass, s[2] / mass, s[3] / mass};
     const int64_t i0 = seg * seg_len, i1 = (i0 + seg_len < N) ? i0 + seg_len : N;
     for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 4 * kVolumeThreads) {
