@@ -1021,7 +1021,8 @@ def main():
         todo = [("sharded_65536_frames", "sharded", with_steps(args, 2, 1))]
         if world == 1:
             todo = [("volumetric_64_frames", "volumetric", with_steps(args, 20, 3)),
-                    ("stream16", "stream16", with_steps(args, 20, 3))] + todo
+                    ("stream16", "stream16", with_steps(args, 20, 3)),
+                    ("training_8_frames", "training", with_steps(args, 20, 5))] + todo
         for key, name, sub in todo:
             torch.cuda.empty_cache()
             rec = run_workload(name, sub, dev, rank, world)
