@@ -201,6 +201,39 @@ def test_unproject_gradient_is_linear_and_deterministic_enough():
     assert scale > 0 and torch.isfinite(grads[0]).all()
 
 
+def test_backward_on_two_overlapping_streams_matches_the_serial_result():
+    """The backward kernels keep no state between calls (workspaces are per call): two training steps issued on two
+    streams that overlap give what each gives alone."""
+    cases = [synth.volumetric_case(4600 + i, 2, 4, n_joints=5, volume_size=32) for i in range(2)]
+    ups = [torch.randn(2, 32, 32, 32, 32, device=DEV), torch.randn(2, 32, 32, 32, 32, device=DEV)]
+    upk = [torch.randn(2, 5, 3, device=DEV), torch.randn(2, 5, 3, device=DEV)]
+
+    def run(i):
+        case = cases[i]
+        f = t(case["features"], True)
+        v = t(case["volumes"], True)
+        proj, coord = t(case["proj"]), t(case["coord_volumes"])
+        op.unproject_heatmaps(f, proj, coord, "softmax").backward(ups[i])
+        kp, _ = op.integrate_tensor_3d_with_coordinates(v, coord)
+        kp.backward(upk[i])
+        return f, v
+
+    serial = [tuple(x.grad.clone() for x in run(i)) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    held = []
+    for rep in range(3):
+        for i, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                held.append((i, run(i)))
+    torch.cuda.synchronize()
+    for i, (f, v) in held:
+        scale = serial[i][0].abs().max().item()
+        assert (f.grad - serial[i][0]).abs().max().item() <= 1e-6 * scale
+        assert torch.equal(v.grad, serial[i][1])
+
+
 def test_arguments_without_a_backward_kernel_still_raise():
     case = synth.volumetric_case(5, 1, 2, n_joints=3, volume_size=8, with_volumes=True)
     f, p, c, v = (t(case[k]) for k in ("features", "proj", "coord_volumes", "volumes"))
