@@ -191,8 +191,8 @@ int mvx_soft_argmax_3d(const float* volumes, const float* coords_volume, int64_t
  * bit-identical to mvx_soft_argmax_3d fed the volume that mvx_build_coord_volumes writes for the same parameters.
  * With softmax and volumes_out (the one-read kernel) the expectation of the voxel index is taken in float64 and mapped
  * through the grid once per volume: the positions it stands for are the exact ones, not their float32 roundings, so
- * the coordinates differ from the tensor-fed result by less than the rounding of one position (about 2e-4 mm for
- * positions of a few metres).  Grid arguments as in mvx_build_coord_volumes (s0, s1, s2 = sx, sy, sz).
+ * the coordinates differ from the tensor-fed result by at most the rounding of one position: one float32 unit in the
+ * last place of the grid's largest position along the axis (1.2e-4 mm for grids reaching 1-2 m).  Grid arguments as in mvx_build_coord_volumes (s0, s1, s2 = sx, sy, sz).
  */
 int mvx_soft_argmax_3d_grid(const float* volumes, const float* position, const float* center, const float* rotation,
                             float step0, float step1, float step2, int swap_yz_flip, int64_t n_frames, int n_volumes,

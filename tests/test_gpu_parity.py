@@ -840,7 +840,12 @@ def test_grid_parameters_instead_of_coordinate_volumes(size, training, transfer,
                 a = op.integrate_tensor_3d_with_coordinates(vols, coord, softmax, return_volumes=ret)
                 b = op.integrate_tensor_3d_with_coordinates(vols, plain, softmax, return_volumes=ret)
                 if softmax and ret and mask == 0:
-                    assert (a[0] - b[0]).abs().max().item() <= 5e-4, (a[0] - b[0]).abs().max().item()
+                    # the one-read kernel maps float64 index moments through the exact grid instead of summing float32
+                    # positions: the results differ by at most the rounding of the positions themselves, one float32
+                    # unit in the last place of the grid's largest position along that axis (1.2e-4 mm at 1-2 m)
+                    reach = coord.abs().amax(dim=(1, 2, 3)).unsqueeze(1)            # (frames, 1, 3)
+                    ulp = torch.nextafter(reach, torch.full_like(reach, float("inf"))) - reach
+                    assert ((a[0] - b[0]).abs() <= ulp).all(), (a[0] - b[0]).abs().max().item()
                     assert torch.allclose(a[1], b[1], rtol=1e-6, atol=0)
                 else:
                     assert torch.equal(a[0], b[0]) and (not ret or torch.equal(a[1], b[1])), (mask, softmax, ret)
