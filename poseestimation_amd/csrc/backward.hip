@@ -300,45 +300,90 @@ __global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
 // Confidence aggregation, before the slice kernel, when the gradient of the confidences is wanted:
 // sum over voxels of (gradient x this view's sample) per (view, channel), which is that gradient.  One workgroup per
 // (frame, run of kConfChunk voxels); lanes as in unproject_view_factors (8 lanes read one whole pixel).  A lane sums
-// its voxels of the run in a register view by view, the workgroup's lanes meet in LDS, and the run's totals go to
+// its voxels of the run in registers, the workgroup's lanes meet in LDS, and the run's totals go to
 // partial[frame][run][view][Cp] (float64) for the slice kernel to add up in run order.
+// NV = 2, 3 or 4 views: rounds of 256 / (Cp / 4) voxels are projected once per (view, voxel) into LDS (dynamic LDS:
+// NV x that many taps) and all views are summed in one sweep; NV = 0 (any number of views): one sweep per view, every
+// lane projecting for itself.
 constexpr int kConfChunk = 2048;
 constexpr int kConfMaxChannels = 64;  // kMapsMaxViews x kConfMaxChannels doubles of LDS
+template <int NV>
 __global__ __launch_bounds__(kBackwardThreads) void unproject_confidence_sums(
     const float* __restrict__ feat_cl, const float* __restrict__ proj, VoxelSource coord, const float* __restrict__ g_vol,
     int runs, int V, int C, int Cp, int H, int W, int64_t n_vox, double sx, double sy, double* __restrict__ partial) {
     __shared__ double acc[kMapsMaxViews * kConfMaxChannels];
+    __shared__ double cam[kMapsMaxViews * 12];
+    extern __shared__ Tap taps[];  // NV > 0: [NV][voxels of a round]
     const int tid = threadIdx.x;
     const int Cq = Cp / 4;
     const int64_t b = blockIdx.x / runs;
     const int run = blockIdx.x % runs;
     for (int i = tid; i < V * Cp; i += kBackwardThreads) acc[i] = 0.0;
+    if (tid < V * 12) cam[tid] = camera_entry(proj + (b * V + tid / 12) * 12, tid % 12, sx, sy);
     __syncthreads();
-    const int q = tid % Cq;
-    const int lanes_per_voxel = Cq, voxels_per_round = kBackwardThreads / lanes_per_voxel;
-    const bool working = tid < voxels_per_round * lanes_per_voxel;
+    const int q = tid % Cq, vl = tid / Cq;
+    const int vpw = kBackwardThreads / Cq;  // voxels of a round
+    const bool working = vl < vpw;
     const int64_t n0 = static_cast<int64_t>(run) * kConfChunk;
     const int64_t n1 = (n0 + kConfChunk < n_vox) ? n0 + kConfChunk : n_vox;
     const size_t map = static_cast<size_t>(H) * W * Cp;
-    for (int u = 0; u < V; ++u) {
-        double Pd[12];
-        load_camera(proj, b * V + u, sx, sy, Pd);
-        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (working) {
-            for (int64_t n = n0 + tid / lanes_per_voxel; n < n1; n += voxels_per_round) {
-                double X, Y, Z;
-                voxel_position(coord, b, n_vox, n, X, Y, Z);
-                const Tap t = project_tap(Pd, X, Y, Z, H, W, 1.0f);
-                float val[4];
-                sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q, val);
+    if constexpr (NV > 0) {
+        float sum[NV][4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float g = (4 * q + k < C) ? g_vol[(b * C + 4 * q + k) * n_vox + n] : 0.0f;
-                    sum[k] = fmaf(g, val[k], sum[k]);
+        for (int u = 0; u < NV; ++u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum[u][k] = 0.0f;
+        }
+        for (int64_t r0 = n0; r0 < n1; r0 += vpw) {
+            for (int i = tid; i < vpw * NV; i += kBackwardThreads) {
+                const int u = i / vpw, at = i - u * vpw;
+                if (r0 + at >= n1) continue;
+                double X, Y, Z;
+                voxel_position(coord, b, n_vox, r0 + at, X, Y, Z);
+                taps[u * vpw + at] = project_tap(cam + u * 12, X, Y, Z, H, W, 1.0f);
+            }
+            __syncthreads();
+            const int64_t n = r0 + vl;
+            if (working && n < n1) {
+                float g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = (4 * q + k < C) ? g_vol[(b * C + 4 * q + k) * n_vox + n] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    float val[4];
+                    sample_quad(feat_cl + (b * V + u) * map, taps[u * vpw + vl], W, Cp, q, val);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sum[u][k] = fmaf(g[k], val[k], sum[u][k]);
                 }
             }
+            __syncthreads();
+        }
+        if (working) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(&acc[u * Cp + 4 * q + k], static_cast<double>(sum[k]));
+            for (int u = 0; u < NV; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&acc[u * Cp + 4 * q + k], static_cast<double>(sum[u][k]));
+            }
+        }
+    } else {
+        for (int u = 0; u < V; ++u) {
+            float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (working) {
+                for (int64_t n = n0 + vl; n < n1; n += vpw) {
+                    double X, Y, Z;
+                    voxel_position(coord, b, n_vox, n, X, Y, Z);
+                    const Tap t = project_tap(cam + u * 12, X, Y, Z, H, W, 1.0f);
+                    float val[4];
+                    sample_quad(feat_cl + (b * V + u) * map, t, W, Cp, q, val);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float g = (4 * q + k < C) ? g_vol[(b * C + 4 * q + k) * n_vox + n] : 0.0f;
+                        sum[k] = fmaf(g, val[k], sum[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&acc[u * Cp + 4 * q + k], static_cast<double>(sum[k]));
+            }
         }
     }
     __syncthreads();
@@ -736,9 +781,21 @@ extern "C" int mvx_unproject_backward(const float* features_cl, const float* pro
             MVX_REQUIRE(aligned16(workspace), MVX_ERR_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", name);
             MVX_REQUIRE(n_frames * conf_runs <= 0x7fffffffLL, MVX_ERR_UNSUPPORTED, "%s: voxel grid too large", name);
             conf_partial = static_cast<double*>(workspace);
-            hipLaunchKernelGGL(unproject_confidence_sums, dim3(static_cast<unsigned>(n_frames * conf_runs)),
-                               dim3(kBackwardThreads), 0, st, features_cl, proj, cd, grad_volumes, conf_runs, V, C, Cp, h, w,
-                               n_voxels, sx, sy, conf_partial);
+            const dim3 conf_grid(static_cast<unsigned>(n_frames * conf_runs));
+            const size_t conf_lds = static_cast<size_t>(V) * (kBackwardThreads / (Cp / 4)) * sizeof(Tap);
+#define MVX_LAUNCH_CONF_SUMS(NV, LDS)                                                                                 \
+    hipLaunchKernelGGL(unproject_confidence_sums<NV>, conf_grid, dim3(kBackwardThreads), LDS, st, features_cl, proj, cd, \
+                       grad_volumes, conf_runs, V, C, Cp, h, w, n_voxels, sx, sy, conf_partial)
+            if (V == 4) {
+                MVX_LAUNCH_CONF_SUMS(4, conf_lds);
+            } else if (V == 3) {
+                MVX_LAUNCH_CONF_SUMS(3, conf_lds);
+            } else if (V == 2) {
+                MVX_LAUNCH_CONF_SUMS(2, conf_lds);
+            } else {
+                MVX_LAUNCH_CONF_SUMS(0, 0);
+            }
+#undef MVX_LAUNCH_CONF_SUMS
             MVX_CHECK_LAUNCH("mvx_unproject_backward (confidence sums)");
         }
         const size_t lds = static_cast<size_t>(band_rows) * slice_row(w) * sizeof(double);
