@@ -231,11 +231,12 @@ int mvx_soft_argmax_3d_static(const float* volumes, const float* coords_volume, 
  * grad_features_cl  [n_frames][n_views][h][w][Cp]     out, channel-last like features_cl; every element written
  * grad_vol_conf     [n_frames][n_views][n_channels]   out, MVX_AGG_CONF only (sum over the voxels of gradient x
  *                                                     sample); written by the call; may be NULL
- * workspace         mvx_unproject_backward_workspace_bytes() bytes of device memory, 16-byte aligned: for MVX_AGG_MAX
- *                   and MVX_AGG_SOFTMAX, the derivative of the aggregate with respect to each view's sample, one float
+ * workspace         mvx_unproject_backward_workspace_bytes() bytes of device memory, 16-byte aligned: for
+ *                   MVX_AGG_SOFTMAX, the derivative of the aggregate with respect to each view's sample, one float
  *                   per (view, channel, voxel) -- the size of the per-view volumes of the reference, 134 MB per frame
- *                   for 4 views x 32 channels x 64^3; for MVX_AGG_CONF the partial sums behind grad_vol_conf (about
- *                   1 KB per frame, view and 2048 voxels); 0 bytes for MVX_AGG_SUM (NULL allowed)
+ *                   for 4 views x 32 channels x 64^3; for MVX_AGG_MAX the first maximal view per (channel, voxel);
+ *                   for MVX_AGG_CONF the partial sums behind grad_vol_conf (about 1 KB per frame, view and 2048
+ *                   voxels); 0 bytes for MVX_AGG_SUM (NULL allowed)
  * Slices of the gradient (two channels of one view's map; larger maps in bands of rows) are accumulated in LDS in
  * float64 and written once: no atomics in global memory, and two runs agree except for float64 rounding before the
  * final conversion.  Shapes that path does not take (rows of more than about 9 700 pixels; with grad_vol_conf more than

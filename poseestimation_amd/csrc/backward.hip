@@ -17,7 +17,8 @@
 //                            axis and project onto a line of pixels, and with rows of 2 W doubles a vertical line
 //                            would fall into one pair of LDS banks.
 //   unproject_view_factors   max and softmax only, before the kernel above: the derivative of the aggregate with
-//                            respect to each view's sample, written once per (view, channel, voxel) into the workspace
+//                            respect to each view's sample (for max: which view holds the maximum), written once per
+//                            (view, channel, voxel) into the workspace
 //                            (the size of the per-view volumes the forward never materialises: V C N floats per frame,
 //                            134 MB for the model's shape), so that the slices sample nothing.  Each of the 16 slices
 //                            of a view sampling for itself uses 8 of the 128 bytes of every pixel it touches, and the
@@ -204,9 +205,10 @@ __device__ __forceinline__ void for_views(int V, F&& f) {
     }
 }
 
-// For max and softmax, before the slice kernel: the derivative of the aggregate with respect to every view's
-// sample, factors[frame][view][channel pair][voxel] (float2) -- 1 for the first view that holds the maximum and 0 for
-// the others (max), s_v (1 + x_v - out) with s the softmax over the views' samples x (softmax: out = sum_v s_v x_v).
+// For max and softmax, before the slice kernel.  softmax: the derivative of the aggregate with respect to every view's
+// sample, factors[frame][view][channel pair][voxel] (float2): s_v (1 + x_v - out) with s the softmax over the views'
+// samples x and out = sum_v s_v x_v.  max: factors[frame][channel pair][voxel] (float2), the index of the first view
+// that holds the maximum (the only one whose sample the aggregate depends on).
 // A workgroup takes 256 / (Cp / 4) consecutive voxels.  First its threads project them, one (view, voxel) each, and
 // leave the taps in LDS; then one lane per (voxel, channel quad), consecutive lanes the quads of one voxel, so that
 // 8 lanes read one whole 128-byte pixel (for 32 channels) and the texture path serves a tap of 8 voxels per
@@ -275,12 +277,15 @@ __global__ __launch_bounds__(kBackwardThreads) void unproject_view_factors(
         rden[k] = 1.0f / den[k];
         out[k] = num[k] * rden[k];
     }
+    if (AGG == MVX_AGG_MAX) {  // one record for all views: which of them holds the maximum
+        float2* row = reinterpret_cast<float2*>(factors) + (static_cast<size_t>(b) * pairs + 2 * q) * n_vox + n;
+        row[0] = make_float2(static_cast<float>(best[0]), static_cast<float>(best[1]));
+        row[n_vox] = make_float2(static_cast<float>(best[2]), static_cast<float>(best[3]));
+        return;
+    }
     for_views<NV>(V, [&](int u) {
         float f[4];
-        if (AGG == MVX_AGG_MAX) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) f[k] = best[k] == u ? 1.0f : 0.0f;
-        } else {
+        {
             float val[4];
             if (kKeep) {
 #pragma unroll
@@ -419,7 +424,6 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
     if (tid < 12) cam[tid] = camera_entry(proj + (b * V + v) * 12, tid, sx, sy);
     __syncthreads();
     const size_t map = static_cast<size_t>(H) * W * Cp;
-    constexpr bool kNeedsValues = AGG == MVX_AGG_MAX || AGG == MVX_AGG_SOFTMAX;
     const bool wants_conf = AGG == MVX_AGG_CONF && g_conf != nullptr;
     float conf[2] = {0.0f, 0.0f};
     if (AGG == MVX_AGG_CONF) {
@@ -434,7 +438,11 @@ __global__ __launch_bounds__(kMapsThreads) void unproject_backward_maps(
         for (int k = 0; k < 2; ++k) g[k] = (c0 + k < C) ? g_vol[(b * C + c0 + k) * n_vox + n] : 0.0f;
         const TapXY t = project_tap_xy(cam, X, Y, Z, H, W, 1.0f);
         float d[2];
-        if (kNeedsValues) {  // the derivative of the aggregate with respect to this view's sample, from the pre-pass
+        if (AGG == MVX_AGG_MAX) {  // the gradient goes to the first view that holds the maximum (from the pre-pass)
+            const float2 f = reinterpret_cast<const float2*>(factors)[(static_cast<size_t>(b) * pairs + pair) * n_vox + n];
+            d[0] = static_cast<int>(f.x) == v ? g[0] : 0.0f;
+            d[1] = static_cast<int>(f.y) == v ? g[1] : 0.0f;
+        } else if (AGG == MVX_AGG_SOFTMAX) {  // the derivative of the aggregate with respect to this view's sample
             const float2 f = reinterpret_cast<const float2*>(factors)[((static_cast<size_t>(b) * V + v) * pairs + pair) * n_vox + n];
             d[0] = g[0] * f.x;
             d[1] = g[1] * f.y;
@@ -680,7 +688,8 @@ extern "C" size_t mvx_unproject_backward_workspace_bytes(int64_t n_frames, int n
     const size_t n_voxels = static_cast<size_t>(vx) * vy * vz;
     if (aggregation == MVX_AGG_CONF)  // per run of voxels, the sums of gradient x sample (float64)
         return static_cast<size_t>(n_frames) * ((n_voxels + mvx::kConfChunk - 1) / mvx::kConfChunk) * n_views * cp * sizeof(double);
-    return static_cast<size_t>(n_frames) * n_views * cp * n_voxels * sizeof(float);
+    // softmax: a factor per (view, channel, voxel); max: the index of the first maximal view per (channel, voxel)
+    return static_cast<size_t>(n_frames) * (aggregation == MVX_AGG_SOFTMAX ? n_views : 1) * cp * n_voxels * sizeof(float);
 }
 
 extern "C" int mvx_unproject_backward(const float* features_cl, const float* proj, const float* coords,
